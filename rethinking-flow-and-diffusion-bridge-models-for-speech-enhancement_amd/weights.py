@@ -1,0 +1,43 @@
+"""Deterministic synthetic weights ("filler") keyed by state-dict name.
+
+No trained checkpoint ships with the reference and none can be fetched, and the
+reference's own default init puts every Conv_1 / NIN_3 / pyramid head at 1e-10
+scale (layers.py:88-91) so a fresh net barely exercises its residual branches
+[SURVEY.md 8(c)].  The filler gives every tensor O(1)-gain values from a
+counter-based generator keyed by the tensor's NAME, so the same numbers can be
+written into the reference module (golden generation, this container only) and
+into the HIP backbone (GPU box) without shipping 262 MB of weights.
+"""
+import zlib
+
+import numpy as np
+
+
+def _rng(key, seed):
+    return np.random.Generator(np.random.Philox(key=[zlib.crc32(key.encode()), seed & 0xFFFFFFFF]))
+
+
+def fill_tensor(key, shape, seed=0):
+    """float32 ndarray for state-dict entry `key` of `shape`."""
+    g = _rng(key, seed)
+    leaf = key.rsplit(".", 1)[-1]
+    parent = key.rsplit(".", 2)[-2] if key.count(".") >= 1 else ""
+    shape = tuple(shape)
+    if "GroupNorm" in key or parent.startswith("GroupNorm"):
+        if leaf == "weight":
+            return (1.0 + 0.1 * g.standard_normal(shape)).astype(np.float32)
+        return (0.1 * g.standard_normal(shape)).astype(np.float32)
+    if leaf == "W" and len(shape) == 1:                     # GaussianFourierProjection.W, scale 16
+        return (16.0 * g.standard_normal(shape)).astype(np.float32)
+    if leaf in ("bias", "b"):
+        return (0.05 * g.standard_normal(shape)).astype(np.float32)
+    if leaf == "W":                                          # NIN: [in, out]
+        fan_in = shape[0]
+    else:                                                    # conv [out,in,k,k] / linear [out,in]
+        fan_in = int(np.prod(shape[1:]))
+    return (g.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+
+
+def fill_state_dict(shapes, seed=0):
+    """{key: float32 ndarray} for a {key: shape} mapping (arch.Spec.param_shapes())."""
+    return {k: fill_tensor(k, s, seed) for k, s in shapes.items()}

@@ -1,0 +1,170 @@
+"""Pins the CPU oracle (oracle/) against outputs of the reference itself
+(tests/golden/*.npz, produced by tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+import torch
+
+import fdbm_amd  # noqa: F401
+from fdbm_amd.arch import Spec, VARIANTS
+from fdbm_amd.weights import fill_state_dict
+from oracle import frontend as ofe
+from oracle import ncsnpp as onet
+from oracle import sampler as osamp
+
+torch.set_num_threads(8)
+MINI64 = dict(nf=64, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,))
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def maxabs(a, b):
+    return float((T(a) - T(b)).abs().max())
+
+
+@pytest.mark.parametrize("tag,kw", [("512", dict(n_fft=512, hop=256, window="sqrthann")),
+                                    ("510", dict(n_fft=510, hop=128, window="hann"))])
+def test_frontend(golden, tag, kw):
+    g = golden("frontend_" + tag)
+    wave = T(g["wave"])
+    S = ofe.stft(wave, **kw)
+    assert S.shape == g["stft"].shape
+    assert maxabs(S, g["stft"]) < 2e-4          # |S| up to ~100; torch uses pocketfft too
+    Sc = ofe.spec_fwd(T(g["stft"]))
+    assert maxabs(Sc, g["spec_fwd"]) < 1e-6
+    assert maxabs(ofe.spec_back(T(g["spec_fwd"])), g["spec_back"]) < 1e-4
+    Y = T(g["spec_fwd"])[None]
+    assert maxabs(ofe.pad_spec(Y, "zero_pad"), g["pad_zero"]) == 0.0
+    assert maxabs(ofe.pad_spec(Y, "reflection"), g["pad_reflect"]) == 0.0
+    x = ofe.istft(T(g["spec_back"]), wave.shape[-1], **kw)
+    assert maxabs(x, g["istft"]) < 2e-6
+    assert maxabs(ofe.spec_fwd(T(g["stft"]), "log"), g["spec_fwd_log"]) < 1e-6
+    assert maxabs(ofe.spec_back(T(g["spec_fwd_log"]), "log"), g["spec_back_log"]) < 1e-4
+
+
+@pytest.mark.parametrize("path,sched", [("sb", "bb"), ("sb", "ve"), ("sb", "vp"), ("sb", "gmax"), ("fm", "ot")])
+def test_coefficients(golden, path, sched):
+    g = golden("coeffs")
+    p = osamp.make_path(path, noise_schedule=sched) if path == "sb" else osamp.make_path(path)
+    exact = sched in ("bb", "ot", "gmax")     # only sqrt/mul/div/add: IEEE-exact in numpy and torch
+    for N in (5, 30, 100):
+        key = f"{path}_{sched}_N{N}"
+        ts = g[key + "_ts"]
+        start, end = (1e-4, 1.0) if path == "fm" else (1.0, 1e-4)
+        assert np.array_equal(osamp.linspace_f32(start, end, N + 1), ts)
+        got = np.array([p.ode_ei(ts[i], ts[i - 1]) for i in range(1, N + 1)], dtype=np.float32)
+        ref = g[key + "_ode_ei"]
+        if exact:
+            assert np.array_equal(got, ref), key
+        else:
+            np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-7)
+        pp = np.array([p.path_param(ts[i]) for i in range(N + 1)], dtype=np.float32)
+        np.testing.assert_allclose(pp, g[key + "_path_param"], rtol=2e-5 if not exact else 0, atol=1e-7 if not exact else 0)
+        if path == "sb":
+            got = np.array([p.sde_ei(ts[i], ts[i - 1]) for i in range(1, N + 1)], dtype=np.float32)
+            np.testing.assert_allclose(got, g[key + "_sde_ei"], rtol=0 if exact else 2e-5, atol=0 if exact else 1e-7)
+            w = np.array([list(p.sde_w(ts[i])) + list(p.ode_w(ts[i])) for i in range(N)], dtype=np.float32)
+            np.testing.assert_allclose(w, g[key + "_sde_ode_w"], rtol=0 if exact else 3e-5, atol=0 if exact else 1e-6)
+
+
+def test_resampling_and_upfirdn(golden):
+    g = golden("ops")
+    x = T(g["resample_x"])
+    assert maxabs(onet.upsample_2d(x), g["upsample"]) < 1e-6
+    assert maxabs(onet.downsample_2d(x), g["downsample"]) < 1e-6
+    k = T(g["ufd_kernel"])
+    assert maxabs(onet.upfirdn2d(x, k, up=2, down=1, pad=(2, 1)), g["ufd_up2_down1"]) < 1e-5
+    assert maxabs(onet.upfirdn2d(x, k, up=1, down=2, pad=(1, 1)), g["ufd_up1_down2"]) < 1e-5
+    assert maxabs(onet.upfirdn2d(x, k, up=2, down=3, pad=(-1, 2)), g["ufd_up2_down3_negpad"]) < 1e-5
+
+
+def _block_sd(shapes_from, prefix="all_modules.9"):
+    return None
+
+
+@pytest.mark.parametrize("name,kw", [("plain", dict(in_ch=32, out_ch=32)), ("widen", dict(in_ch=32, out_ch=64)),
+                                     ("up", dict(in_ch=32, up=True)), ("down", dict(in_ch=32, down=True)),
+                                     ("cat", dict(in_ch=96, out_ch=32))])
+def test_resblock(golden, name, kw):
+    g = golden("ops")
+    in_ch, out_ch = kw["in_ch"], kw.get("out_ch", kw["in_ch"])
+    p = "all_modules.9"
+    shapes = {f"{p}.GroupNorm_0.weight": (in_ch,), f"{p}.GroupNorm_0.bias": (in_ch,),
+              f"{p}.Conv_0.weight": (out_ch, in_ch, 3, 3), f"{p}.Conv_0.bias": (out_ch,),
+              f"{p}.Dense_0.weight": (out_ch, 64), f"{p}.Dense_0.bias": (out_ch,),
+              f"{p}.GroupNorm_1.weight": (out_ch,), f"{p}.GroupNorm_1.bias": (out_ch,),
+              f"{p}.Conv_1.weight": (out_ch, out_ch, 3, 3), f"{p}.Conv_1.bias": (out_ch,)}
+    if in_ch != out_ch or kw.get("up") or kw.get("down"):
+        shapes.update({f"{p}.Conv_2.weight": (out_ch, in_ch, 1, 1), f"{p}.Conv_2.bias": (out_ch,)})
+    sd = onet.to_torch(fill_state_dict(shapes, seed=3))
+    y = onet.resblock(sd, p, T(g[f"res_{name}_x"]), T(g["temb"]), up=kw.get("up", False), down=kw.get("down", False))
+    assert maxabs(y, g[f"res_{name}_y"]) < 2e-5
+
+
+def test_attn_and_combine(golden):
+    g = golden("ops")
+    p = "all_modules.9"
+    shapes = {f"{p}.GroupNorm_0.weight": (32,), f"{p}.GroupNorm_0.bias": (32,)}
+    for j in range(4):
+        shapes.update({f"{p}.NIN_{j}.W": (32, 32), f"{p}.NIN_{j}.b": (32,)})
+    sd = onet.to_torch(fill_state_dict(shapes, seed=3))
+    assert maxabs(onet.attnblock(sd, p, T(g["attn_x"])), g["attn_y"]) < 1e-5
+    sd = onet.to_torch(fill_state_dict({f"{p}.Conv_0.weight": (32, 4, 1, 1), f"{p}.Conv_0.bias": (32,)}, seed=3))
+    y = torch.nn.functional.conv2d(T(g["comb_p"]), sd[f"{p}.Conv_0.weight"], sd[f"{p}.Conv_0.bias"]) + T(g["comb_h"])
+    assert maxabs(y, g["comb_y"]) < 1e-5
+
+
+def _model(name):
+    hp = MINI64 if name == "mini64" else VARIANTS["ncsnpp_" + name]
+    return onet.Model(fill_state_dict(Spec(**hp).param_shapes(), seed=0), hp), hp
+
+
+@pytest.mark.parametrize("name", ["mini64", "v2_5M"])
+def test_backbone(golden, name):
+    g = golden("backbone_" + name)
+    model, _ = _model(name)
+    out = model(T(g["x"]), T(g["y"]), T(g["t"]))
+    assert out.shape == g["out"].shape
+    err = maxabs(out, g["out"])
+    scale = float(np.abs(g["out"]).max())
+    assert err < 2e-5 * max(scale, 1.0), (err, scale)
+
+
+SAMPLER_CASES = [
+    ("sb_bb_ode_ei_N5", "sb", dict(noise_schedule="bb"), 5, "ode_ei", {}),
+    ("fm_ot_ode_ei_N5", "fm", {}, 5, "ode_ei", {}),
+    ("sb_bb_sde_ei_N5", "sb", dict(noise_schedule="bb"), 5, "sde_ei", {}),
+    ("sb_ve_sde_ei_N4", "sb", dict(noise_schedule="ve"), 4, "sde_ei", {}),
+    ("sb_bb_pc_N4", "sb", dict(noise_schedule="bb"), 4, "pc", dict(corrector="ald", snr=0.5, denoise=False)),
+    ("sb_vp_pc_N3", "sb", dict(noise_schedule="vp"), 3, "pc", dict(corrector="langevin", snr=0.3, denoise=True)),
+]
+
+
+@pytest.mark.parametrize("tag,path,pkw,N,kind,skw", SAMPLER_CASES)
+def test_samplers(golden, tag, path, pkw, N, kind, skw):
+    g = golden("samplers")
+    model, _ = _model("v2_5M")
+    y = T(g["y"])
+    smp = osamp.Sampler(path, N=N, **pkw)
+    gen = torch.Generator().manual_seed(1234)
+    out = getattr(smp, kind)(model, y, gen, **skw)
+    err = maxabs(out, g[tag])
+    noise_floor = maxabs(g["sb_bb_ode_ei_N5"], g["sb_bb_ode_ei_N5_1thread"])
+    assert err < 1e-4, (tag, err, noise_floor)
+
+
+def test_sampler_ode_int(golden):
+    g = golden("samplers")
+    model, _ = _model("v2_5M")
+    smp = osamp.Sampler("sb", N=5, noise_schedule="bb")
+    out = smp.ode_int(model, T(g["y"]), torch.Generator().manual_seed(1234), rtol=1e-2, atol=1e-2)
+    assert maxabs(out, g["sb_bb_ode_int"]) < 2e-3     # adaptive RK45: step decisions amplify fp noise
+
+
+def test_sampler_batched(golden):
+    g = golden("samplers")
+    model, _ = _model("mini64")
+    smp = osamp.Sampler("sb", N=3, noise_schedule="bb")
+    out = smp.ode_ei(model, T(g["mini64_y"]), torch.Generator().manual_seed(99))
+    assert maxabs(out, g["mini64_sb_bb_ode_ei_N3"]) < 1e-4

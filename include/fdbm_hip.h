@@ -1,0 +1,217 @@
+/*
+ * fdbm_hip.h - C ABI of libfdbm_hip.so, the MI355X (gfx950) kernels behind the
+ * reverse-sampling path of flow / diffusion-bridge speech enhancement.
+ *
+ * Conventions:
+ *   - extern "C", plain pointers and sizes, no torch / C++ types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library never
+ *     allocates, never frees, never synchronises; every call only enqueues kernels on
+ *     `stream` (a hipStream_t passed as void*), so calls are HIP-graph capturable.
+ *   - return value: 0 = ok, non-zero = error; fdbm_last_error() gives the message of the
+ *     last failure on the calling thread.  No C++ exception crosses the boundary.
+ *   - activations are NHWC ("[B][H=freq][W=time][C]", C contiguous); dtype codes below.
+ *
+ * Each entry point names the reference interface it stands in for (file:line under
+ * the reference checkout).
+ */
+#ifndef FDBM_HIP_H
+#define FDBM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FDBM_F32 0
+#define FDBM_BF16 1
+
+#define FDBM_MAX_SEG 4
+
+const char* fdbm_last_error(void);
+int fdbm_version(void);
+
+/* ------------------------------------------------------------------ sampler state update
+ * out = (wa[b]*a + wb[b]*b) + wc[b]*c over complex64 [B][n_complex] viewed as floats; each
+ * product and sum rounded separately (no FMA contraction).  c / wc may be NULL (2 terms).
+ * Replaces the 5 elementwise kernels of `xt = w_xt*xt + w_s*s + w_y*y` (fdbm/bridge.py:83),
+ * `... + w_z*z` (:109) and prior_sampling's `y*b + z*sigma` (:48).  out may alias a. */
+int fdbm_bridge_update(void* out, const void* a, const void* b, const void* c,
+                       const float* wa, const float* wb, const float* wc,
+                       int B, int64_t n_complex, void* stream);
+
+/* Euler-Maruyama predictor move (fdbm/util/predictors.py:44-51 + ProbabilityPathSB.sde,
+ * fdbm/bridge.py:294-306): drift = (wx*x + ws*s) + wy*y; x_mean = x + drift*dt;
+ * x_new = x_mean + (gd*sqrt(-dt))*z.  Weights are [B] device floats; dt a host scalar. */
+int fdbm_pc_predictor(void* x_new, void* x_mean, const void* x, const void* s, const void* y,
+                      const void* z, const float* wx, const float* ws, const float* wy,
+                      const float* gd, float dt, int B, int64_t n_complex, void* stream);
+
+/* Langevin corrector move (fdbm/util/correctors.py:44-53,72-79 + Bridge.score_fn,
+ * fdbm/bridge.py:51-54): score = -(x - (a*s + b*y))/den; x_mean = x + step*score;
+ * x_new = x_mean + noise*noise_scale.  a, b, den, step, noise_scale: [B] device floats. */
+int fdbm_pc_corrector(void* x_new, void* x_mean, const void* x, const void* s, const void* y,
+                      const void* noise, const float* a, const float* b, const float* den,
+                      const float* step, const float* noise_scale, int B, int64_t n_complex,
+                      void* stream);
+
+/* ------------------------------------------------------------------ network input / output
+ * cat(x.re, x.im, y.re, y.im) with the Nyquist row dropped when F == 257
+ * (fdbm/backbones/ncsnpp_v2.py:247-250): complex64 [B][1][F][T] x2 -> f32 [B][Fn][T][4]. */
+int fdbm_pack_input(float* out, const void* x, const void* y, int B, int F, int Fn, int T,
+                    void* stream);
+
+/* output_layer 1x1 conv 4->2, NHWC->complex, zero Nyquist row re-appended
+ * (ncsnpp_v2.py:392-399): f32 [B][Fn][T][4] -> complex64 [B][1][F][T].  w: [2][4], b: [2]. */
+int fdbm_unpack_output(void* out, const float* pyr, const float* w, const float* b,
+                       int B, int F, int Fn, int T, void* stream);
+
+/* ------------------------------------------------------------------ time embedding
+ * GaussianFourierProjection(log t) -> Linear -> SiLU -> Linear, then SiLU again (every
+ * consumer applies act(temb) first): out f32 [B][4nf] = silu(temb).  The Fourier argument
+ * is formed as ((log t * W) * 2) * pi in fp32 (layerspp.py:40; ncsnpp_v2.py:252-270). */
+int fdbm_temb(float* out_act, const float* t, const float* fourier_w, const float* w1,
+              const float* b1, const float* w2, const float* b2, float* scratch, int B, int nf,
+              void* stream);
+
+/* All res-blocks' Dense_0(act(temb)) at once (layerspp.py:262-263): out[b][r] =
+ * bias[r] + sum_k w[r][k]*act[b][k];  w: [R][K] f32 (all blocks' rows concatenated). */
+int fdbm_dense_rows(float* out, const float* act, const float* w, const float* bias, int B, int R,
+                    int K, void* stream);
+
+/* ------------------------------------------------------------------ stem (4 -> nf, 3x3)
+ * modules[3] conv3x3 (ncsnpp_v2.py:154,278): in f32 [B][H][W][4], w f32 [nf][3][3][4]
+ * (o, ky, kx, c), out dtype `dt_out` [B][H][W][nf]. */
+int fdbm_conv_stem(void* out, const float* in, const float* w, const float* bias, int B, int H,
+                   int W, int nf, int dt_out, void* stream);
+
+/* ------------------------------------------------------------------ GroupNorm
+ * nn.GroupNorm(min(C/4,32), C, eps=1e-6) (layerspp.py:67,219,231; ncsnpp_v2.py:205,217)
+ * over a VIRTUAL CONCAT of up to two NHWC tensors (torch.cat([h, hs.pop()], 1),
+ * ncsnpp_v2.py:330).  Stage 1: per-(b, split, group) partial sums; stage 2: mean/rstd. */
+int fdbm_gn_stats(float* partial /*[B][nsplit][G][2]*/, const void* src0, int C0,
+                  const void* src1, int C1, int B, int HW, int G, int nsplit, int dtype,
+                  void* stream);
+int fdbm_gn_finalize(float* mean_rstd /*[B][G][2]*/, const float* partial, int B, int nsplit,
+                     int G, int64_t count, float eps, void* stream);
+/* out = act(gn(cat(src0, src1))) written as one NHWC tensor of C0+C1 channels. */
+int fdbm_gn_apply(void* out, const void* src0, int C0, const void* src1, int C1,
+                  const float* mean_rstd, const float* gamma, const float* beta, int B, int HW,
+                  int G, int silu, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ FIR resampling
+ * Generic upfirdn2d, the reference's own native-op boundary
+ * (ncsnpp_utils/op/upfirdn2d.cpp:4-23, upfirdn2d_kernel.cu:107-207,209-368):
+ * input f32 [major][in_h][in_w][minor], kernel f32 [kh][kw], out f32
+ * [major][out_h][out_w][minor]. */
+int fdbm_upfirdn2d(float* out, const float* in, const float* kernel, int major, int in_h, int in_w,
+                   int minor, int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                   int pad_x0, int pad_x1, int pad_y0, int pad_y1, void* stream);
+
+/* Fast path for the only configuration the network uses: FIR [1,3,3,1], factor 2
+ * (upsample_2d / downsample_2d, up_or_down_sampling.py:195-257), NHWC, dtype in {f32,bf16}.
+ * One read of x produces up to two outputs: out_plain = resample(x) and, when mean_rstd is
+ * non-NULL, out_act = resample(silu(gn(x))) (ResnetBlockBigGANpp.forward,
+ * layerspp.py:243-258).  Either output pointer may be NULL.  up != 0: upsample. */
+int fdbm_resample2x(void* out_plain, void* out_act, const void* in, const float* mean_rstd,
+                    const float* gamma, const float* beta, int B, int H, int W, int C, int G,
+                    int up, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ convolution (implicit GEMM on MFMA)
+ * nn.Conv2d 3x3 pad 1 / 1x1 (layers.py:100-105,118-124) and NIN (layers.py:546-555) as one
+ * GEMM  out[m][n] = sum_k A[m][k] W[n][k]  with m = (b, y, x) pixels and the K axis a list
+ * of SEGMENTS, each an NHWC source tensor slice with 1 or 9 taps: a virtual concat is two
+ * 9-tap segments, the res-block's 1x1 shortcut (Conv_2) is an extra 1-tap segment summed in
+ * the same accumulator.  Weights are pre-packed by the host as [kstep][CoutPad][KC]
+ * (KC = 64 bf16 / 32 f32 elements = 128 bytes), zero padded.
+ * Epilogue: v = acc + bias[n] + tbias[b][n];  if res: v = (v + res[m][n]);  out = v*scale. */
+typedef struct {
+  const void* src;   /* NHWC tensor [B][H][W][C]                                   */
+  int32_t C;         /* its channel count (pixel stride in elements)               */
+  int32_t coff;      /* first channel of the slice                                 */
+  int32_t cin;       /* channels in the slice                                      */
+  int32_t taps;      /* 1 (1x1 / NIN / shortcut) or 9 (3x3, pad 1)                 */
+} fdbm_conv_seg;
+
+typedef struct {
+  fdbm_conv_seg seg[FDBM_MAX_SEG];
+  int32_t nseg;
+  const void* w;        /* packed weights, dtype = dt_in                            */
+  const float* bias;    /* [Cout] or NULL                                           */
+  const float* tbias;   /* [B][tbias_stride] or NULL (Dense_0(act(temb)) rows)      */
+  int32_t tbias_stride;
+  const void* res;      /* [M][Cout] dtype dt_out or NULL                           */
+  float scale;          /* 1/sqrt(2) with skip_rescale, else 1                      */
+  void* out;            /* [M][Cout] dtype dt_out                                   */
+  int32_t B, H, W, Cout, CoutPad;
+  int32_t dt_in;        /* FDBM_F32 | FDBM_BF16 : sources and packed weights        */
+  int32_t dt_out;       /* FDBM_F32 | FDBM_BF16 (f32 out with bf16 in is allowed)   */
+} fdbm_conv_args;
+
+int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream);
+/* elements per k-step for a dtype (64 for bf16, 32 for f32) */
+int fdbm_conv_kc(int dtype);
+
+/* Combine('sum'): out = conv1x1(4->C)(pyr) + h (layerspp.py:52-57; ncsnpp_v2.py:302-305).
+ * pyr f32 [M][4], w f32 [C][4], bias f32 [C], h/out dtype [M][C]; out may alias h. */
+int fdbm_combine(void* out, const void* h, const float* pyr, const float* w, const float* bias,
+                 int64_t M, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ attention
+ * AttnBlockpp core (layerspp.py:82-86): softmax(q k^T * C^-0.5) v over all H*W tokens, one
+ * head.  qkv: [B][N][3C] (q | k | v per token, dtype), out [B][N][C] dtype. */
+int fdbm_attention(void* out, const void* qkv, int B, int N, int C, int dtype, void* stream);
+
+/* ------------------------------------------------------------------ front-end
+ * SpecsDataModule.stft / istft (fdbm/data_module.py:201-229; torch.stft centre, reflect pad,
+ * one-sided), spec_fwd / spec_back (:173-199) fused in, pad_spec (fdbm/util/other.py:76-90).
+ * n_fft must be even and <= 1024; window f32 [n_fft].
+ * transform: 0 none, 1 exponent (|X|^e e^{j arg X} * f), 2 log. */
+int fdbm_stft(void* spec /*c64 [B][n_fft/2+1][Tpad]*/, const float* wave /*[B][L]*/,
+              const float* window, int B, int L, int n_fft, int hop, int frames, int Tpad,
+              int pad_mode /*0 zero, 1 reflection*/, int transform, float factor, float exponent,
+              void* stream);
+int fdbm_istft(float* wave /*[B][L]*/, const void* spec /*c64 [B][bins][Tpad]*/,
+               const float* window, float* frames_ws /*[B][frames][n_fft]*/, int B, int L,
+               int n_fft, int hop, int frames, int Tpad, int transform, float factor,
+               float exponent, void* stream);
+
+/* Stand-alone spec_fwd (inverse=0) / spec_back (inverse=1) on complex64 data
+ * (fdbm/data_module.py:173-199) and pad_spec (fdbm/util/other.py:76-90; mode 0 zero_pad,
+ * 1 reflection, 2 replication; in [rows][T] -> out [rows][Tpad] complex64). */
+int fdbm_spec_transform(void* out, const void* in, int64_t n_complex, int transform, float factor,
+                        float exponent, int inverse, void* stream);
+int fdbm_pad_spec(void* out, const void* in, int64_t rows, int T, int Tpad, int mode, void* stream);
+
+/* ------------------------------------------------------------------ recorded programs
+ * A backbone forward is a fixed list of the calls above.  The host records it once
+ * (opcode + argument block per op) and replays it with one call; this is what
+ * `fdbm_ncsnpp_forward(ctx, ...)` of SURVEY.md 8(b) amounts to. */
+typedef struct {
+  int32_t opcode;        /* FDBM_OP_* */
+  int32_t reserved;
+  int64_t iarg[24];      /* integer / pointer arguments, meaning per opcode (program.cpp) */
+  float farg[4];
+} fdbm_op;
+
+#define FDBM_OP_CONV 1        /* iarg[0] = (const fdbm_conv_args*) host pointer */
+#define FDBM_OP_GN_STATS 2
+#define FDBM_OP_GN_FINALIZE 3
+#define FDBM_OP_GN_APPLY 4
+#define FDBM_OP_RESAMPLE 5
+#define FDBM_OP_COMBINE 6
+#define FDBM_OP_ATTENTION 7
+#define FDBM_OP_STEM 8
+#define FDBM_OP_PACK 9
+#define FDBM_OP_UNPACK 10
+#define FDBM_OP_TEMB 11
+#define FDBM_OP_DENSE 12
+#define FDBM_OP_UPDATE 13
+
+int fdbm_run_program(const fdbm_op* ops_host, int n_ops, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FDBM_HIP_H */

@@ -5,6 +5,7 @@ inference path).  Import as ``fdbm_amd`` (see ../fdbm_amd.py).
 from .registry import (Registry, BridgeRegistry, BackboneRegistry,  # noqa: F401
                        PredictorRegistry, CorrectorRegistry)
 from .bridge import Bridge, NoiseSource, complex_randn  # noqa: F401
+from . import backbone as _backbone  # noqa: F401  (registers ncsnpp_v2 / _5M / _16M / _37M)
 
 __all__ = ["Registry", "BridgeRegistry", "BackboneRegistry", "PredictorRegistry",
            "CorrectorRegistry", "Bridge", "NoiseSource", "complex_randn"]

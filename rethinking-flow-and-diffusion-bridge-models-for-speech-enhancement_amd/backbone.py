@@ -1,0 +1,254 @@
+"""HIP-backed NCSN++ v2 backbones behind ``BackboneRegistry``.
+
+Drop-in for fdbm.backbones.ncsnpp_v2 (NCSNpp_v2 and the _5M/_16M/_37M sizes,
+ncsnpp_v2.py:36-453): classes take ``**kwargs`` (unknown ones swallowed), offer
+``add_argparse_args`` and are callable as ``model(x, y, t)`` with complex64
+``[B,1,F,T]`` x, y and float ``[B]`` t, returning complex64 ``[B,1,F,T]``.
+State-dict keys are the reference's (``all_modules.<i>....``, ``output_layer.*``).
+
+Every arithmetic step runs in libfdbm_hip.so (program.py records the launch list);
+this file only moves weights to the device and owns the per-shape programs and
+sampler graphs.  There is no CPU path: constructing a backbone without a HIP
+device or without the built library raises.
+"""
+import numpy as np
+import torch
+
+from . import hip
+from .arch import Spec, VARIANTS, IN_CH
+from .program import Program, pack_conv_weight
+from .registry import BackboneRegistry
+from .weights import fill_state_dict
+
+
+def _as_f32(v, device):
+    if not torch.is_tensor(v):
+        v = torch.from_numpy(np.asarray(v))
+    return v.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class HipNCSNpp:
+    """One backbone instance: architecture + device weights + per-shape programs."""
+
+    variant = None          # set by the registered subclasses
+
+    @staticmethod
+    def add_argparse_args(parser):
+        parser.add_argument("--nf", type=int, default=128)
+        parser.add_argument("--ch_mult", type=int, nargs="+", default=[1, 1, 2, 2, 2, 2, 2])
+        parser.add_argument("--num_res_blocks", type=int, default=2)
+        parser.add_argument("--attn_resolutions", type=int, nargs="+", default=[16])
+        return parser
+
+    def __init__(self, nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,),
+                 dtype=torch.bfloat16, device=None, state=None, seed=0, **unused_kwargs):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipNCSNpp needs a HIP device (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        hip.lib()                                   # fails loudly if the extension is not built
+        self.spec = Spec(nf=nf, ch_mult=ch_mult, num_res_blocks=num_res_blocks,
+                         attn_resolutions=attn_resolutions)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.dtype = dtype
+        self._programs = {}
+        self._graphs = {}
+        self.sample_graph = None                    # installed by enable_graphs()
+        if state is None:                           # random-init weights of this architecture
+            state = fill_state_dict(self.spec.param_shapes(), seed=seed)
+        self.load_state_dict(state)
+        self.enable_graphs(True)
+
+    # nn.Module-ish conveniences used by the reference drivers
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __call__(self, x, y, t):
+        return self.forward(x, y, t)
+
+    # ---- weights -----------------------------------------------------------------------
+    def load_state_dict(self, state):
+        """state: {key: array/tensor} under the reference's keys (an optional 'dnn.' prefix,
+        as in Lightning checkpoints of BridgeModel, is stripped)."""
+        state = {(k[4:] if k.startswith("dnn.") else k): v for k, v in state.items()}
+        shapes = self.spec.param_shapes()
+        missing = [k for k in shapes if k not in state]
+        if missing:
+            raise KeyError(f"state dict misses {len(missing)} tensors, e.g. {missing[:3]}")
+        for k, shp in shapes.items():
+            if tuple(state[k].shape) != tuple(shp):
+                raise ValueError(f"{k}: shape {tuple(state[k].shape)} != expected {tuple(shp)}")
+        dev, dt = self.device, self.dtype
+        kc = hip.conv_kc(hip.dt_code(dt))
+        g = lambda k: _as_f32(state[k], dev)
+        self.w = {}
+        dense_w, dense_b, self.dense_off = [], [], {}
+        rows = 0
+        for m in self.spec.mods:
+            p = m.prefix
+            if m.kind == "fourier":
+                self.fourier_w = g(p + ".W")
+            elif m.kind == "linear":
+                if m.idx == 1:
+                    self.lin1_w, self.lin1_b = g(p + ".weight"), g(p + ".bias")
+                else:
+                    self.lin2_w, self.lin2_b = g(p + ".weight"), g(p + ".bias")
+            elif m.kind == "conv3x3" and m.in_ch == IN_CH:            # stem: [nf][ky][kx][c]
+                self.w[m.idx] = dict(w=g(p + ".weight").permute(0, 2, 3, 1).contiguous(), b=g(p + ".bias"))
+            elif m.kind == "conv3x3":                                  # pyramid head C -> 4
+                wp, pad = pack_conv_weight([(g(p + ".weight"), 9)], kc, dt, dev)
+                self.w[m.idx] = dict(w=wp, pad=pad, b=g(p + ".bias"))
+            elif m.kind == "groupnorm":
+                self.w[m.idx] = dict(w=g(p + ".weight"), b=g(p + ".bias"))
+            elif m.kind == "combine":
+                self.w[m.idx] = dict(w=g(p + ".Conv_0.weight").reshape(m.out_ch, IN_CH).contiguous(),
+                                     b=g(p + ".Conv_0.bias"))
+            elif m.kind == "attn":
+                qkv_w = torch.cat([g(f"{p}.NIN_{j}.W").t() for j in range(3)], 0)[:, :, None, None]
+                qkv, qpad = pack_conv_weight([(qkv_w, 1)], kc, dt, dev)
+                proj, ppad = pack_conv_weight([(g(p + ".NIN_3.W").t()[:, :, None, None], 1)], kc, dt, dev)
+                self.w[m.idx] = dict(gn_w=g(p + ".GroupNorm_0.weight"), gn_b=g(p + ".GroupNorm_0.bias"),
+                                     qkv=qkv, qkv_pad=qpad,
+                                     qkv_b=torch.cat([g(f"{p}.NIN_{j}.b") for j in range(3)]).contiguous(),
+                                     proj=proj, proj_pad=ppad, proj_b=g(p + ".NIN_3.b"))
+            elif m.kind == "resblock":
+                has2 = (p + ".Conv_2.weight") in shapes
+                c0, c0pad = pack_conv_weight([(g(p + ".Conv_0.weight"), 9)], kc, dt, dev)
+                segs = [(g(p + ".Conv_1.weight"), 9)]
+                b1 = g(p + ".Conv_1.bias")
+                if has2:
+                    w2 = g(p + ".Conv_2.weight")
+                    # the 1x1 shortcut rides in the same GEMM: one extra K segment per source
+                    # tensor of the (virtual) concat, split at the skip boundary
+                    split = self._concat_split(m)
+                    off = 0
+                    for c in split:
+                        segs.append((w2[:, off:off + c], 1))
+                        off += c
+                    b1 = (b1 + g(p + ".Conv_2.bias")).contiguous()
+                c1, c1pad = pack_conv_weight(segs, kc, dt, dev)
+                self.w[m.idx] = dict(gn0_w=g(p + ".GroupNorm_0.weight"), gn0_b=g(p + ".GroupNorm_0.bias"),
+                                     conv0=c0, conv0_pad=c0pad, conv0_b=g(p + ".Conv_0.bias"),
+                                     gn1_w=g(p + ".GroupNorm_1.weight"), gn1_b=g(p + ".GroupNorm_1.bias"),
+                                     conv1=c1, conv1_pad=c1pad, conv1_b=b1, has_conv2=has2)
+                dense_w.append(g(p + ".Dense_0.weight"))
+                dense_b.append(g(p + ".Dense_0.bias"))
+                self.dense_off[m.idx] = rows
+                rows += m.out_ch
+            else:
+                raise AssertionError(m.kind)
+        ol = self.spec.output_layer
+        self.w[-1] = dict(w=g("output_layer.weight").reshape(2, IN_CH).contiguous(), b=g("output_layer.bias"))
+        self.dense_w = torch.cat(dense_w, 0).contiguous()
+        self.dense_b = torch.cat(dense_b, 0).contiguous()
+        self.dense_rows = rows
+        self._programs.clear()
+        self._graphs.clear()
+        return self
+
+    def _concat_split(self, mod):
+        """Channel counts of the source tensors feeding res-block `mod` (1 entry, or 2 for the
+        up path's cat([h, skip]))."""
+        if not hasattr(self, "_splits"):
+            self._splits = _concat_splits(self.spec)
+        return self._splits[mod.idx]
+
+    def dense_out_ptr(self, prog, mod_idx):
+        return prog.dense_out.data_ptr() + 4 * self.dense_off[mod_idx]
+
+    # ---- programs ------------------------------------------------------------------------
+    def program(self, B, F, T):
+        key = (B, F, T)
+        if key not in self._programs:
+            with torch.cuda.device(self.device):
+                self._programs[key] = Program(self, B, F, T)
+        return self._programs[key]
+
+    def forward(self, x, y, t):
+        if not (x.is_cuda and y.is_cuda):
+            raise RuntimeError("HipNCSNpp.forward needs HIP tensors (no CPU fallback)")
+        B, _, F, T = x.shape
+        prog = self.program(B, F, T)
+        prog.x_in.copy_(x)
+        prog.y_in.copy_(y)
+        prog.t_in.copy_(t.to(device=self.device, dtype=torch.float32).reshape(B))
+        prog.run()
+        return prog.s_out.clone()
+
+    def flops_per_forward(self, F=256, T=256):
+        return 2 * self.spec.macs_per_forward(F, T)
+
+    # ---- whole-sampler HIP graphs -------------------------------------------------------
+    def enable_graphs(self, on=True):
+        from .engine import sample_with_graph
+        self.sample_graph = (lambda bridge, y, kind, noise: sample_with_graph(self, bridge, y, kind, noise)) if on else None
+
+
+def _concat_splits(spec):
+    """mod.idx -> list of source channel counts, replaying the skip-stack bookkeeping of
+    ncsnpp_v2.py:148-233."""
+    out = {}
+    nf = spec.nf
+    hs_c = [nf]
+    in_ch = nf
+    it = iter(spec.mods[4:])
+    for lvl in range(spec.num_resolutions):
+        for _ in range(spec.num_res_blocks):
+            m = next(it)
+            out[m.idx] = [in_ch]
+            in_ch = m.out_ch
+            if spec.all_resolutions[lvl] in spec.attn_resolutions:
+                next(it)
+            hs_c.append(in_ch)
+        if lvl != spec.num_resolutions - 1:
+            m = next(it)
+            out[m.idx] = [in_ch]
+            next(it)            # combine
+            hs_c.append(in_ch)
+    m = next(it); out[m.idx] = [in_ch]
+    next(it)
+    m = next(it); out[m.idx] = [in_ch]
+    for lvl in reversed(range(spec.num_resolutions)):
+        for _ in range(spec.num_res_blocks + 1):
+            m = next(it)
+            skip = hs_c.pop()
+            out[m.idx] = [in_ch, skip]
+            in_ch = m.out_ch
+        if spec.all_resolutions[lvl] in spec.attn_resolutions:
+            next(it)
+        next(it); next(it)      # groupnorm, head conv
+        if lvl != 0:
+            m = next(it)
+            out[m.idx] = [in_ch]
+    return out
+
+
+def _register(name):
+    kw = VARIANTS[name]
+
+    @BackboneRegistry.register(name)
+    class _Net(HipNCSNpp):
+        variant = name
+
+        def __init__(self, **kwargs):
+            for k in ("nf", "ch_mult", "num_res_blocks", "attn_resolutions"):
+                if name != "ncsnpp_v2":
+                    kwargs.pop(k, None)
+            merged = dict(kw)
+            merged.update(kwargs)
+            super().__init__(**merged)
+
+        @staticmethod
+        def add_argparse_args(parser):
+            return HipNCSNpp.add_argparse_args(parser) if name == "ncsnpp_v2" else parser
+
+    _Net.__name__ = "NCSNpp_v2" + name[len("ncsnpp_v2"):]
+    return _Net
+
+
+NCSNpp_v2 = _register("ncsnpp_v2")
+NCSNpp_v2_5M = _register("ncsnpp_v2_5M")
+NCSNpp_v2_16M = _register("ncsnpp_v2_16M")
+NCSNpp_v2_37M = _register("ncsnpp_v2_37M")

@@ -1,0 +1,149 @@
+// attention.hip - single-head global attention of AttnBlockpp:
+//   out[b][i][:] = sum_j softmax_j(q_i . k_j * C^-0.5) v_j      over all N = H*W tokens.
+//
+// 0.04 % of the network's flops and latency-bound (N = T tokens at the 16-row level, 4*T/64
+// at the bottleneck), so this is an fp32 flash-style kernel on the vector ALU: 16 queries
+// per workgroup, keys/values streamed through LDS in tiles of 32, online softmax with
+// 16-lane shuffle reductions, fp32 accumulation whatever the storage dtype.
+#include "common.h"
+
+#define ATT_QB 16
+#define ATT_KB 32
+
+template <typename T>
+__global__ void __launch_bounds__(256) attention_kernel(T* __restrict__ out, const T* __restrict__ qkv,
+                                                        int N, int C, float scale) {
+  constexpr int VW = DT<T>::vecw;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int CP = C + 4;                       // padded row (16-byte shift per row: conflict-free b128)
+  float* q_s = sm;                            // [QB][CP]
+  float* k_s = q_s + ATT_QB * CP;             // [KB][CP]
+  float* v_s = k_s + ATT_KB * CP;             // [KB][CP]
+  float* p_s = v_s + ATT_KB * CP;             // [QB][KB]
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * ATT_QB;
+  const int tid = threadIdx.x;
+  const int tq = tid >> 4;                    // query within the block
+  const int tj = tid & 15;
+  const T* base = qkv + (int64_t)b * N * 3 * C;
+  const int nvec = C / VW;
+
+  for (int i = tid; i < ATT_QB * nvec; i += 256) {
+    const int r = i / nvec, v = i % nvec;
+    float x[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) x[k] = 0.f;
+    if (q0 + r < N) Vec16<T>::load(base + (int64_t)(q0 + r) * 3 * C + v * VW, x);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) q_s[r * CP + v * VW + k] = x[k];
+  }
+
+  float m_run = -INFINITY, l_run = 0.f;
+  float o[16];                                // channels tj*4.. within each 64-channel slab
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  const int nslab = (C + 63) / 64;            // each thread: 4 channels per 64-channel slab
+
+  for (int k0 = 0; k0 < N; k0 += ATT_KB) {
+    __syncthreads();
+    for (int i = tid; i < ATT_KB * nvec; i += 256) {
+      const int r = i / nvec, v = i % nvec;
+      float kx[VW], vx[VW];
+#pragma unroll
+      for (int k = 0; k < VW; ++k) kx[k] = vx[k] = 0.f;
+      if (k0 + r < N) {
+        const T* row = base + (int64_t)(k0 + r) * 3 * C + v * VW;
+        Vec16<T>::load(row + C, kx);
+        Vec16<T>::load(row + 2 * C, vx);
+      }
+#pragma unroll
+      for (int k = 0; k < VW; ++k) {
+        k_s[r * CP + v * VW + k] = kx[k];
+        v_s[r * CP + v * VW + k] = vx[k];
+      }
+    }
+    __syncthreads();
+    // scores for keys tj and tj+16
+    float s0 = 0.f, s1 = 0.f;
+    const float* qr = q_s + tq * CP;
+    const float* kr0 = k_s + tj * CP;
+    const float* kr1 = k_s + (tj + 16) * CP;
+    for (int c = 0; c < C; c += 4) {
+      const f32x4 qv = *reinterpret_cast<const f32x4*>(qr + c);
+      const f32x4 a = *reinterpret_cast<const f32x4*>(kr0 + c);
+      const f32x4 bq = *reinterpret_cast<const f32x4*>(kr1 + c);
+      s0 += qv[0] * a[0] + qv[1] * a[1] + qv[2] * a[2] + qv[3] * a[3];
+      s1 += qv[0] * bq[0] + qv[1] * bq[1] + qv[2] * bq[2] + qv[3] * bq[3];
+    }
+    s0 = (k0 + tj < N) ? s0 * scale : -INFINITY;
+    s1 = (k0 + tj + 16 < N) ? s1 * scale : -INFINITY;
+    float tmax = fmaxf(s0, s1);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+    const float m_new = fmaxf(m_run, tmax);
+    const float p0 = __expf(s0 - m_new), p1 = __expf(s1 - m_new);
+    float psum = p0 + p1;
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) psum += __shfl_xor(psum, off);
+    const float alpha = __expf(m_run - m_new);     // exp(-inf) = 0 on the first tile
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+    p_s[tq * ATT_KB + tj] = p0;
+    p_s[tq * ATT_KB + tj + 16] = p1;
+    __syncthreads();
+    // O[tq][channels of this thread] = O*alpha + sum_key p * v
+    const float* pr = p_s + tq * ATT_KB;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      if (sl < nslab && sl * 64 + tj * 4 < C) {
+        f32x4 accv = {o[sl * 4] * alpha, o[sl * 4 + 1] * alpha, o[sl * 4 + 2] * alpha, o[sl * 4 + 3] * alpha};
+        const float* vp = v_s + sl * 64 + tj * 4;
+        for (int key = 0; key < ATT_KB; ++key) {
+          const float pw = pr[key];
+          const f32x4 vv = *reinterpret_cast<const f32x4*>(vp + key * CP);
+          accv[0] += pw * vv[0]; accv[1] += pw * vv[1]; accv[2] += pw * vv[2]; accv[3] += pw * vv[3];
+        }
+        o[sl * 4] = accv[0]; o[sl * 4 + 1] = accv[1]; o[sl * 4 + 2] = accv[2]; o[sl * 4 + 3] = accv[3];
+      }
+    }
+  }
+  if (q0 + tq < N) {
+    const float inv = 1.0f / l_run;
+    T* dst = out + ((int64_t)b * N + q0 + tq) * C;
+#pragma unroll
+    for (int sl = 0; sl < 4; ++sl) {
+      if (sl < nslab && sl * 64 + tj * 4 < C) {
+        const float r4[4] = {o[sl * 4] * inv, o[sl * 4 + 1] * inv, o[sl * 4 + 2] * inv, o[sl * 4 + 3] * inv};
+        if constexpr (sizeof(T) == 2) {
+          bf16x4 t = {(bf16_t)r4[0], (bf16_t)r4[1], (bf16_t)r4[2], (bf16_t)r4[3]};
+          *reinterpret_cast<bf16x4*>(dst + sl * 64 + tj * 4) = t;
+        } else {
+          *reinterpret_cast<f32x4*>(dst + sl * 64 + tj * 4) = f32x4{r4[0], r4[1], r4[2], r4[3]};
+        }
+      }
+    }
+  }
+}
+
+extern "C" int fdbm_attention(void* out, const void* qkv, int B, int N, int C, int dtype, void* stream) {
+  FDBM_CHECK(out && qkv, "fdbm_attention: null pointer");
+  FDBM_CHECK(C % 8 == 0 && C <= 256, "fdbm_attention: C=%d must be a multiple of 8, <= 256", C);
+  FDBM_CHECK(B > 0 && N > 0, "fdbm_attention: bad shape");
+  const size_t smem = ((size_t)(ATT_QB + 2 * ATT_KB) * (C + 4) + ATT_QB * ATT_KB) * sizeof(float);
+  dim3 grid(cdiv(N, ATT_QB), B);
+  const float scale = 1.0f / sqrtf((float)C);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FDBM_BF16) {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); set = true; }
+    attention_kernel<bf16_t><<<grid, 256, smem, st>>>((bf16_t*)out, (const bf16_t*)qkv, N, C, scale);
+  } else if (dtype == FDBM_F32) {
+    static bool set = false;
+    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); set = true; }
+    attention_kernel<float><<<grid, 256, smem, st>>>((float*)out, (const float*)qkv, N, C, scale);
+  } else {
+    FDBM_CHECK(false, "fdbm_attention: bad dtype %d", dtype);
+  }
+  FDBM_LAUNCH_CHECK("fdbm_attention");
+  return 0;
+}

@@ -1,0 +1,425 @@
+// elementwise.hip - HBM-bound passes of the sampling path: sampler state update,
+// predictor / corrector moves, network input packing / output projection, Combine,
+// time embedding and the 4->nf stem convolution.  All fp32 math; 16-byte accesses.
+#include "common.h"
+
+// ---------------------------------------------------------------------------------
+// sampler state update: out = (wa*a + wb*b) + wc*c   (complex64 viewed as floats)
+// ---------------------------------------------------------------------------------
+template <bool HAS_C>
+__global__ void __launch_bounds__(256) bridge_update_kernel(
+    float* __restrict__ out, const float* __restrict__ a, const float* __restrict__ b,
+    const float* __restrict__ c, const float* __restrict__ wa, const float* __restrict__ wb,
+    const float* __restrict__ wc, int64_t nvec /*float4 per sample*/, int64_t tail_start,
+    int64_t nfloat) {
+  const int bi = blockIdx.y;
+  const float fa = wa[bi], fb = wb[bi];
+  const float fc = HAS_C ? wc[bi] : 0.f;
+  const int64_t base = (int64_t)bi * nfloat;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const f32x4 va = *reinterpret_cast<const f32x4*>(a + base + 4 * i);
+    const f32x4 vb = *reinterpret_cast<const f32x4*>(b + base + 4 * i);
+    f32x4 vc = {0, 0, 0, 0};
+    if (HAS_C) vc = *reinterpret_cast<const f32x4*>(c + base + 4 * i);
+    f32x4 r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // each product and each sum rounded on its own: the SB first step cancels
+      // 1794.79*y - 1793.82*y, so the rounding order is part of the contract.
+      float s = __fadd_rn(__fmul_rn(fa, va[k]), __fmul_rn(fb, vb[k]));
+      if (HAS_C) s = __fadd_rn(s, __fmul_rn(fc, vc[k]));
+      r[k] = s;
+    }
+    *reinterpret_cast<f32x4*>(out + base + 4 * i) = r;
+  }
+  // scalar tail (n not a multiple of 4 floats)
+  if (blockIdx.x == 0) {
+    for (int64_t i = tail_start + threadIdx.x; i < nfloat; i += blockDim.x) {
+      float s = __fadd_rn(__fmul_rn(fa, a[base + i]), __fmul_rn(fb, b[base + i]));
+      if (HAS_C) s = __fadd_rn(s, __fmul_rn(fc, c[base + i]));
+      out[base + i] = s;
+    }
+  }
+}
+
+extern "C" int fdbm_bridge_update(void* out, const void* a, const void* b, const void* c,
+                                  const float* wa, const float* wb, const float* wc, int B,
+                                  int64_t n_complex, void* stream) {
+  FDBM_CHECK(out && a && b && wa && wb, "fdbm_bridge_update: null pointer");
+  FDBM_CHECK((c == nullptr) == (wc == nullptr), "fdbm_bridge_update: c and wc must both be set or both NULL");
+  FDBM_CHECK(B > 0 && n_complex >= 0, "fdbm_bridge_update: bad sizes B=%d n=%lld", B, (long long)n_complex);
+  if (n_complex == 0) return 0;
+  const int64_t nfloat = 2 * n_complex;
+  const bool aligned = ((nfloat % 4) == 0) || B == 1;
+  const int64_t nvec = aligned ? nfloat / 4 : 0;
+  const int64_t tail = nvec * 4;
+  int gx = (int)((nvec + 255) / 256);
+  if (gx < 1) gx = 1;
+  if (gx > 2048) gx = 2048;
+  dim3 grid(gx, B);
+  hipStream_t st = (hipStream_t)stream;
+  if (c)
+    bridge_update_kernel<true><<<grid, 256, 0, st>>>((float*)out, (const float*)a, (const float*)b,
+                                                     (const float*)c, wa, wb, wc, nvec, tail, nfloat);
+  else
+    bridge_update_kernel<false><<<grid, 256, 0, st>>>((float*)out, (const float*)a, (const float*)b,
+                                                      nullptr, wa, wb, nullptr, nvec, tail, nfloat);
+  FDBM_LAUNCH_CHECK("fdbm_bridge_update");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// predictor / corrector moves
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pc_predictor_kernel(
+    float* __restrict__ xn, float* __restrict__ xm, const float* __restrict__ x,
+    const float* __restrict__ s, const float* __restrict__ y, const float* __restrict__ z,
+    const float* wx, const float* ws, const float* wy, const float* gd, float dt, float sq,
+    int64_t nfloat) {
+  const int bi = blockIdx.y;
+  const float fx = wx[bi], fs = ws[bi], fy = wy[bi];
+  const float gz = __fmul_rn(gd[bi], sq);
+  const int64_t base = (int64_t)bi * nfloat;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nfloat;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = x[base + i];
+    float drift = __fadd_rn(__fadd_rn(__fmul_rn(fx, xv), __fmul_rn(fs, s[base + i])),
+                            __fmul_rn(fy, y[base + i]));
+    float mean = __fadd_rn(xv, __fmul_rn(drift, dt));
+    xm[base + i] = mean;
+    xn[base + i] = __fadd_rn(mean, __fmul_rn(gz, z[base + i]));
+  }
+}
+
+extern "C" int fdbm_pc_predictor(void* x_new, void* x_mean, const void* x, const void* s,
+                                 const void* y, const void* z, const float* wx, const float* ws,
+                                 const float* wy, const float* gd, float dt, int B,
+                                 int64_t n_complex, void* stream) {
+  FDBM_CHECK(x_new && x_mean && x && s && y && z && wx && ws && wy && gd, "fdbm_pc_predictor: null pointer");
+  FDBM_CHECK(dt <= 0.f, "fdbm_pc_predictor: dt must be <= 0 (reverse time), got %g", dt);
+  const int64_t nfloat = 2 * n_complex;
+  int gx = (int)((nfloat + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  if (gx < 1) gx = 1;
+  pc_predictor_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(
+      (float*)x_new, (float*)x_mean, (const float*)x, (const float*)s, (const float*)y,
+      (const float*)z, wx, ws, wy, gd, dt, sqrtf(-dt), nfloat);
+  FDBM_LAUNCH_CHECK("fdbm_pc_predictor");
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) pc_corrector_kernel(
+    float* __restrict__ xn, float* __restrict__ xm, const float* __restrict__ x,
+    const float* __restrict__ s, const float* __restrict__ y, const float* __restrict__ nz,
+    const float* a, const float* b, const float* den, const float* step, const float* nscale,
+    int64_t nfloat) {
+  const int bi = blockIdx.y;
+  const float fa = a[bi], fb = b[bi], fd = den[bi], fst = step[bi], fn = nscale[bi];
+  const int64_t base = (int64_t)bi * nfloat;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nfloat;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float xv = x[base + i];
+    float mean = __fadd_rn(__fmul_rn(fa, s[base + i]), __fmul_rn(fb, y[base + i]));
+    float score = __fdiv_rn(-__fsub_rn(xv, mean), fd);
+    float m = __fadd_rn(xv, __fmul_rn(fst, score));
+    xm[base + i] = m;
+    xn[base + i] = __fadd_rn(m, __fmul_rn(nz[base + i], fn));
+  }
+}
+
+extern "C" int fdbm_pc_corrector(void* x_new, void* x_mean, const void* x, const void* s,
+                                 const void* y, const void* noise, const float* a, const float* b,
+                                 const float* den, const float* step, const float* noise_scale,
+                                 int B, int64_t n_complex, void* stream) {
+  FDBM_CHECK(x_new && x_mean && x && s && y && noise && a && b && den && step && noise_scale,
+             "fdbm_pc_corrector: null pointer");
+  const int64_t nfloat = 2 * n_complex;
+  int gx = (int)((nfloat + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  if (gx < 1) gx = 1;
+  pc_corrector_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(
+      (float*)x_new, (float*)x_mean, (const float*)x, (const float*)s, (const float*)y,
+      (const float*)noise, a, b, den, step, noise_scale, nfloat);
+  FDBM_LAUNCH_CHECK("fdbm_pc_corrector");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// network input / output
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) pack_input_kernel(f32x4* __restrict__ out,
+                                                         const f32x2* __restrict__ x,
+                                                         const f32x2* __restrict__ y, int F, int Fn,
+                                                         int T, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const int64_t r = i / T;
+    const int f = (int)(r % Fn);
+    const int64_t b = r / Fn;
+    const int64_t src = (b * F + f) * T + t;
+    const f32x2 xv = x[src], yv = y[src];
+    f32x4 o = {xv[0], xv[1], yv[0], yv[1]};
+    out[i] = o;
+  }
+}
+
+extern "C" int fdbm_pack_input(float* out, const void* x, const void* y, int B, int F, int Fn, int T,
+                               void* stream) {
+  FDBM_CHECK(out && x && y, "fdbm_pack_input: null pointer");
+  FDBM_CHECK(Fn <= F && Fn > 0 && T > 0 && B > 0, "fdbm_pack_input: bad shape");
+  const int64_t total = (int64_t)B * Fn * T;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  pack_input_kernel<<<g, 256, 0, (hipStream_t)stream>>>((f32x4*)out, (const f32x2*)x,
+                                                        (const f32x2*)y, F, Fn, T, total);
+  FDBM_LAUNCH_CHECK("fdbm_pack_input");
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) unpack_output_kernel(f32x2* __restrict__ out,
+                                                            const f32x4* __restrict__ pyr,
+                                                            const float* __restrict__ w,
+                                                            const float* __restrict__ bias, int F,
+                                                            int Fn, int T, int64_t total) {
+  const float w00 = w[0], w01 = w[1], w02 = w[2], w03 = w[3];
+  const float w10 = w[4], w11 = w[5], w12 = w[6], w13 = w[7];
+  const float b0 = bias[0], b1 = bias[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = (int)(i % T);
+    const int64_t r = i / T;
+    const int f = (int)(r % F);
+    const int64_t b = r / F;
+    f32x2 o = {0.f, 0.f};
+    if (f < Fn) {
+      const f32x4 p = pyr[(b * Fn + f) * T + t];
+      o[0] = b0 + (((w00 * p[0] + w01 * p[1]) + w02 * p[2]) + w03 * p[3]);
+      o[1] = b1 + (((w10 * p[0] + w11 * p[1]) + w12 * p[2]) + w13 * p[3]);
+    }
+    out[i] = o;
+  }
+}
+
+extern "C" int fdbm_unpack_output(void* out, const float* pyr, const float* w, const float* b, int B,
+                                  int F, int Fn, int T, void* stream) {
+  FDBM_CHECK(out && pyr && w && b, "fdbm_unpack_output: null pointer");
+  const int64_t total = (int64_t)B * F * T;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  unpack_output_kernel<<<g, 256, 0, (hipStream_t)stream>>>((f32x2*)out, (const f32x4*)pyr, w, b, F,
+                                                           Fn, T, total);
+  FDBM_LAUNCH_CHECK("fdbm_unpack_output");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// Combine('sum'): out = h + bias + W[C][4] * pyr[4]
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) combine_kernel(T* __restrict__ out, const T* __restrict__ h,
+                                                      const f32x4* __restrict__ pyr,
+                                                      const f32x4* __restrict__ w,
+                                                      const float* __restrict__ bias, int64_t M,
+                                                      int C) {
+  constexpr int VW = DT<T>::vecw;
+  const int nvec = C / VW;
+  const int64_t total = M * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int v = (int)(i % nvec);
+    const int64_t m = i / nvec;
+    const f32x4 p = pyr[m];
+    float hv[VW];
+    Vec16<T>::load(h + m * C + v * VW, hv);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      const int c = v * VW + k;
+      const f32x4 wc = w[c];
+      hv[k] = hv[k] + (bias[c] + (((wc[0] * p[0] + wc[1] * p[1]) + wc[2] * p[2]) + wc[3] * p[3]));
+    }
+    Vec16<T>::store(out + m * C + v * VW, hv);
+  }
+}
+
+extern "C" int fdbm_combine(void* out, const void* h, const float* pyr, const float* w,
+                            const float* bias, int64_t M, int C, int dtype, void* stream) {
+  FDBM_CHECK(out && h && pyr && w && bias, "fdbm_combine: null pointer");
+  FDBM_CHECK(C % 8 == 0, "fdbm_combine: C=%d must be a multiple of 8", C);
+  const int vw = dtype == FDBM_BF16 ? 8 : 4;
+  const int64_t total = M * (C / vw);
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FDBM_BF16)
+    combine_kernel<bf16_t><<<g, 256, 0, st>>>((bf16_t*)out, (const bf16_t*)h, (const f32x4*)pyr,
+                                              (const f32x4*)w, bias, M, C);
+  else if (dtype == FDBM_F32)
+    combine_kernel<float><<<g, 256, 0, st>>>((float*)out, (const float*)h, (const f32x4*)pyr,
+                                             (const f32x4*)w, bias, M, C);
+  else
+    FDBM_CHECK(false, "fdbm_combine: bad dtype %d", dtype);
+  FDBM_LAUNCH_CHECK("fdbm_combine");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// time embedding: dense rows (one wave per output row), optional Fourier front
+// ---------------------------------------------------------------------------------
+#define DENSE_BCHUNK 8
+template <bool FOURIER, bool SILU>
+__global__ void __launch_bounds__(256) dense_rows_kernel(float* __restrict__ out,
+                                                         const float* __restrict__ act,
+                                                         const float* __restrict__ t,
+                                                         const float* __restrict__ fw,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ bias, int B, int R,
+                                                         int K) {
+  extern __shared__ float s_act[];  // [DENSE_BCHUNK][K]
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int r = blockIdx.x * 4 + wave;
+  for (int b0 = 0; b0 < B; b0 += DENSE_BCHUNK) {
+    const int nb = min(DENSE_BCHUNK, B - b0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb * K; i += blockDim.x) {
+      const int bb = i / K, k = i % K;
+      float v;
+      if (FOURIER) {
+        const int nf = K / 2;
+        const int j = k < nf ? k : k - nf;
+        // ((log t * W) * 2) * pi, every product rounded to fp32 (layerspp.py:40)
+        const float arg = __fmul_rn(__fmul_rn(__fmul_rn(logf(t[b0 + bb]), fw[j]), 2.0f), 3.14159274101257324f);
+        v = k < nf ? sinf(arg) : cosf(arg);
+      } else {
+        v = act[(int64_t)(b0 + bb) * K + k];
+      }
+      s_act[i] = v;
+    }
+    __syncthreads();
+    if (r < R) {
+      float acc[DENSE_BCHUNK];
+#pragma unroll
+      for (int bb = 0; bb < DENSE_BCHUNK; ++bb) acc[bb] = 0.f;
+      for (int k = lane; k < K; k += 64) {
+        const float wv = w[(int64_t)r * K + k];
+#pragma unroll
+        for (int bb = 0; bb < DENSE_BCHUNK; ++bb)
+          if (bb < nb) acc[bb] += wv * s_act[bb * K + k];
+      }
+#pragma unroll
+      for (int bb = 0; bb < DENSE_BCHUNK; ++bb) {
+        float v = acc[bb];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0 && bb < nb) {
+          v += bias[r];
+          out[(int64_t)(b0 + bb) * R + r] = SILU ? silu_f(v) : v;
+        }
+      }
+    }
+  }
+}
+
+extern "C" int fdbm_dense_rows(float* out, const float* act, const float* w, const float* bias,
+                               int B, int R, int K, void* stream) {
+  FDBM_CHECK(out && act && w && bias, "fdbm_dense_rows: null pointer");
+  FDBM_CHECK(K * DENSE_BCHUNK * 4 <= 65536, "fdbm_dense_rows: K=%d too large", K);
+  dense_rows_kernel<false, false><<<cdiv(R, 4), 256, DENSE_BCHUNK * K * sizeof(float),
+                                    (hipStream_t)stream>>>(out, act, nullptr, nullptr, w, bias, B, R, K);
+  FDBM_LAUNCH_CHECK("fdbm_dense_rows");
+  return 0;
+}
+
+extern "C" int fdbm_temb(float* out_act, const float* t, const float* fourier_w, const float* w1,
+                         const float* b1, const float* w2, const float* b2, float* scratch, int B,
+                         int nf, void* stream) {
+  FDBM_CHECK(out_act && t && fourier_w && w1 && b1 && w2 && b2 && scratch, "fdbm_temb: null pointer");
+  const int E = 2 * nf, D = 4 * nf;
+  FDBM_CHECK(D * DENSE_BCHUNK * 4 <= 65536, "fdbm_temb: nf=%d too large", nf);
+  hipStream_t st = (hipStream_t)stream;
+  // scratch[b][D] = silu(W1 * fourier(log t) + b1)
+  dense_rows_kernel<true, true><<<cdiv(D, 4), 256, DENSE_BCHUNK * E * sizeof(float), st>>>(
+      scratch, nullptr, t, fourier_w, w1, b1, B, D, E);
+  FDBM_LAUNCH_CHECK("fdbm_temb/1");
+  // out_act[b][D] = silu(W2 * scratch + b2)   (consumers all take act(temb))
+  dense_rows_kernel<false, true><<<cdiv(D, 4), 256, DENSE_BCHUNK * D * sizeof(float), st>>>(
+      out_act, scratch, nullptr, nullptr, w2, b2, B, D, D);
+  FDBM_LAUNCH_CHECK("fdbm_temb/2");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
+// stem: conv3x3 4 -> nf, direct (K = 36 is far too small for MFMA tiles; HBM-bound
+// on the nf-channel output write)
+// ---------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
+                                                        const f32x4* __restrict__ in,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias, int B, int H,
+                                                        int W, int nf) {
+  extern __shared__ float s_w[];  // [nf][36] + [nf] bias
+  for (int i = threadIdx.x; i < nf * 36; i += blockDim.x) s_w[i] = w[i];
+  for (int i = threadIdx.x; i < nf; i += blockDim.x) s_w[nf * 36 + i] = bias[i];
+  __syncthreads();
+  const int ncg = nf / 8;   // 8 output channels per thread
+  const int64_t total = (int64_t)B * H * W * ncg;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int cg = (int)(idx % ncg);
+  const int64_t p = idx / ncg;
+  const int x = (int)(p % W);
+  const int y = (int)((p / W) % H);
+  const int64_t b = p / ((int64_t)W * H);
+  f32x4 tap[9];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int iy = y + ky - 1, ix = x + kx - 1;
+      f32x4 v = {0, 0, 0, 0};
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = in[(b * H + iy) * W + ix];
+      tap[ky * 3 + kx] = v;
+    }
+  float o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int oc = cg * 8 + j;
+    const float* wr = s_w + oc * 36;
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+      acc += wr[k * 4 + 0] * tap[k][0];
+      acc += wr[k * 4 + 1] * tap[k][1];
+      acc += wr[k * 4 + 2] * tap[k][2];
+      acc += wr[k * 4 + 3] * tap[k][3];
+    }
+    o[j] = acc + s_w[nf * 36 + oc];
+  }
+  T* dst = out + p * nf + cg * 8;
+  if constexpr (sizeof(T) == 2) {
+    Vec16<T>::store(dst, o);
+  } else {
+    Vec16<T>::store(dst, o);
+    Vec16<T>::store(dst + 4, o + 4);
+  }
+}
+
+extern "C" int fdbm_conv_stem(void* out, const float* in, const float* w, const float* bias, int B,
+                              int H, int W, int nf, int dt_out, void* stream) {
+  FDBM_CHECK(out && in && w && bias, "fdbm_conv_stem: null pointer");
+  FDBM_CHECK(nf % 8 == 0 && nf <= 256, "fdbm_conv_stem: nf=%d unsupported", nf);
+  const int64_t total = (int64_t)B * H * W * (nf / 8);
+  const size_t smem = (size_t)nf * 37 * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  if (dt_out == FDBM_BF16)
+    conv_stem_kernel<bf16_t><<<cdiv(total, 256), 256, smem, st>>>((bf16_t*)out, (const f32x4*)in, w, bias, B, H, W, nf);
+  else if (dt_out == FDBM_F32)
+    conv_stem_kernel<float><<<cdiv(total, 256), 256, smem, st>>>((float*)out, (const f32x4*)in, w, bias, B, H, W, nf);
+  else
+    FDBM_CHECK(false, "fdbm_conv_stem: bad dtype %d", dt_out);
+  FDBM_LAUNCH_CHECK("fdbm_conv_stem");
+  return 0;
+}

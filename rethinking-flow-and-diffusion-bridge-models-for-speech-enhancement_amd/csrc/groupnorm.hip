@@ -1,0 +1,196 @@
+// groupnorm.hip - GroupNorm(min(C/4,32), eps 1e-6) over NHWC tensors, including the
+// virtual concat of two tensors (a group may straddle the two sources).
+//
+//   stats   : per (b, split, group) partial (sum, sumsq), deterministic reduction order
+//   finalize: partials -> (mean, rstd) in fp64
+//   apply   : y = act(x*scale + shift), scale = rstd*gamma, shift = beta - mean*scale
+//
+// HBM-bound: stats reads the tensor once; apply reads once and writes once (16-byte accesses,
+// channel axis contiguous, consecutive threads on consecutive 16-byte vectors).
+#include "common.h"
+
+#define GN_MAXC 1024
+
+template <typename T>
+__global__ void __launch_bounds__(256) gn_stats_kernel(float* __restrict__ partial,
+                                                       const T* __restrict__ src0, int C0,
+                                                       const T* __restrict__ src1, int C1, int HW,
+                                                       int G, int nsplit) {
+  constexpr int VW = DT<T>::vecw;
+  __shared__ float s_part[2][256 * VW];   // per-thread channel sums
+  __shared__ float s_ch[2][GN_MAXC];      // per-channel sums
+  const int b = blockIdx.y, split = blockIdx.x;
+  const int C = C0 + C1;
+  const int per = (HW + nsplit - 1) / nsplit;
+  const int p0 = split * per;
+  const int p1 = min(HW, p0 + per);
+
+  for (int s = 0; s < 2; ++s) {
+    const T* src = s == 0 ? src0 : src1;
+    const int Cs = s == 0 ? C0 : C1;
+    const int cbase = s == 0 ? 0 : C0;
+    if (Cs == 0) continue;
+    const int nvec = Cs / VW;               // vectors per pixel
+    const int ppi = 256 / nvec;             // pixels per block iteration
+    const int v = threadIdx.x % nvec;
+    const int pl = threadIdx.x / nvec;
+    float sum[VW], sq[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) sum[k] = sq[k] = 0.f;
+    if (pl < ppi) {
+      const T* base = src + (int64_t)b * HW * Cs + v * VW;
+      for (int p = p0 + pl; p < p1; p += ppi) {
+        float x[VW];
+        Vec16<T>::load(base + (int64_t)p * Cs, x);
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+          sum[k] += x[k];
+          sq[k] += x[k] * x[k];
+        }
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      s_part[0][threadIdx.x * VW + k] = sum[k];
+      s_part[1][threadIdx.x * VW + k] = sq[k];
+    }
+    __syncthreads();
+    // channel c of this source: threads pl*nvec + c/VW, element c%VW, pl = 0..ppi-1
+    for (int c = threadIdx.x; c < Cs; c += blockDim.x) {
+      float a0 = 0.f, a1 = 0.f;
+      for (int q = 0; q < ppi; ++q) {
+        const int th = q * nvec + c / VW;
+        a0 += s_part[0][th * VW + c % VW];
+        a1 += s_part[1][th * VW + c % VW];
+      }
+      s_ch[0][cbase + c] = a0;
+      s_ch[1][cbase + c] = a1;
+    }
+    __syncthreads();
+  }
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float a0 = 0.f, a1 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+      a0 += s_ch[0][c];
+      a1 += s_ch[1][c];
+    }
+    float* dst = partial + (((int64_t)b * nsplit + split) * G + g) * 2;
+    dst[0] = a0;
+    dst[1] = a1;
+  }
+}
+
+extern "C" int fdbm_gn_stats(float* partial, const void* src0, int C0, const void* src1, int C1,
+                             int B, int HW, int G, int nsplit, int dtype, void* stream) {
+  FDBM_CHECK(partial && src0, "fdbm_gn_stats: null pointer");
+  FDBM_CHECK((src1 != nullptr) == (C1 > 0), "fdbm_gn_stats: src1/C1 mismatch");
+  const int vw = dtype == FDBM_BF16 ? 8 : 4;
+  FDBM_CHECK(C0 % vw == 0 && C1 % vw == 0, "fdbm_gn_stats: channels (%d,%d) must be multiples of %d", C0, C1, vw);
+  FDBM_CHECK(C0 / vw <= 256 && C1 / vw <= 256 && C0 + C1 <= GN_MAXC, "fdbm_gn_stats: too many channels");
+  FDBM_CHECK(G > 0 && (C0 + C1) % G == 0, "fdbm_gn_stats: C=%d not divisible by G=%d", C0 + C1, G);
+  FDBM_CHECK(nsplit >= 1 && nsplit <= HW, "fdbm_gn_stats: bad nsplit %d (HW=%d)", nsplit, HW);
+  dim3 grid(nsplit, B);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FDBM_BF16)
+    gn_stats_kernel<bf16_t><<<grid, 256, 0, st>>>(partial, (const bf16_t*)src0, C0, (const bf16_t*)src1, C1, HW, G, nsplit);
+  else if (dtype == FDBM_F32)
+    gn_stats_kernel<float><<<grid, 256, 0, st>>>(partial, (const float*)src0, C0, (const float*)src1, C1, HW, G, nsplit);
+  else
+    FDBM_CHECK(false, "fdbm_gn_stats: bad dtype %d", dtype);
+  FDBM_LAUNCH_CHECK("fdbm_gn_stats");
+  return 0;
+}
+
+__global__ void gn_finalize_kernel(float* __restrict__ mr, const float* __restrict__ partial, int B,
+                                   int nsplit, int G, double inv_count, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * G) return;
+  const int b = i / G, g = i % G;
+  double s0 = 0.0, s1 = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* p = partial + (((int64_t)b * nsplit + s) * G + g) * 2;
+    s0 += (double)p[0];
+    s1 += (double)p[1];
+  }
+  const double mean = s0 * inv_count;
+  double var = s1 * inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  mr[2 * i] = (float)mean;
+  mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+extern "C" int fdbm_gn_finalize(float* mean_rstd, const float* partial, int B, int nsplit, int G,
+                                int64_t count, float eps, void* stream) {
+  FDBM_CHECK(mean_rstd && partial && count > 0, "fdbm_gn_finalize: bad arguments");
+  gn_finalize_kernel<<<cdiv(B * G, 64), 64, 0, (hipStream_t)stream>>>(mean_rstd, partial, B, nsplit, G,
+                                                                     1.0 / (double)count, eps);
+  FDBM_LAUNCH_CHECK("fdbm_gn_finalize");
+  return 0;
+}
+
+template <typename T, bool SILU>
+__global__ void __launch_bounds__(256) gn_apply_kernel(T* __restrict__ out, const T* __restrict__ src0,
+                                                       int C0, const T* __restrict__ src1, int C1,
+                                                       const float* __restrict__ mr,
+                                                       const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, int HW, int G,
+                                                       int chunks) {
+  constexpr int VW = DT<T>::vecw;
+  __shared__ float s_scale[GN_MAXC], s_shift[GN_MAXC];
+  const int b = blockIdx.y;
+  const int C = C0 + C1;
+  const int cpg = C / G;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float mean = mr[(b * G + g) * 2], rstd = mr[(b * G + g) * 2 + 1];
+    const float sc = rstd * gamma[c];
+    s_scale[c] = sc;
+    s_shift[c] = beta[c] - mean * sc;
+  }
+  __syncthreads();
+  const int nvec = C / VW;
+  const int64_t total = (int64_t)HW * nvec;
+  const int64_t per = (total + chunks - 1) / chunks;
+  const int64_t i0 = blockIdx.x * per;
+  const int64_t i1 = min(total, i0 + per);
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const int v = (int)(i % nvec);
+    const int64_t p = i / nvec;
+    const int c = v * VW;
+    const T* src = c < C0 ? src0 + ((int64_t)b * HW + p) * C0 + c
+                          : src1 + ((int64_t)b * HW + p) * C1 + (c - C0);
+    float x[VW];
+    Vec16<T>::load(src, x);
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      float y = x[k] * s_scale[c + k] + s_shift[c + k];
+      x[k] = SILU ? silu_f(y) : y;
+    }
+    Vec16<T>::store(out + ((int64_t)b * HW + p) * C + c, x);
+  }
+}
+
+extern "C" int fdbm_gn_apply(void* out, const void* src0, int C0, const void* src1, int C1,
+                             const float* mean_rstd, const float* gamma, const float* beta, int B,
+                             int HW, int G, int silu, int dtype, void* stream) {
+  FDBM_CHECK(out && src0 && mean_rstd && gamma && beta, "fdbm_gn_apply: null pointer");
+  FDBM_CHECK((src1 != nullptr) == (C1 > 0), "fdbm_gn_apply: src1/C1 mismatch");
+  const int vw = dtype == FDBM_BF16 ? 8 : 4;
+  const int C = C0 + C1;
+  FDBM_CHECK(C0 % vw == 0 && C1 % vw == 0 && C <= GN_MAXC && C % G == 0, "fdbm_gn_apply: bad channels (%d,%d) G=%d", C0, C1, G);
+  const int64_t total = (int64_t)HW * (C / vw);
+  int chunks = (int)((total + 2047) / 2048);
+  if (chunks > 1024) chunks = 1024;
+  if (chunks < 1) chunks = 1;
+  dim3 grid(chunks, B);
+  hipStream_t st = (hipStream_t)stream;
+#define GN_APPLY(TT, S) gn_apply_kernel<TT, S><<<grid, 256, 0, st>>>((TT*)out, (const TT*)src0, C0, (const TT*)src1, C1, mean_rstd, gamma, beta, HW, G, chunks)
+  if (dtype == FDBM_BF16) { if (silu) GN_APPLY(bf16_t, true); else GN_APPLY(bf16_t, false); }
+  else if (dtype == FDBM_F32) { if (silu) GN_APPLY(float, true); else GN_APPLY(float, false); }
+  else FDBM_CHECK(false, "fdbm_gn_apply: bad dtype %d", dtype);
+#undef GN_APPLY
+  FDBM_LAUNCH_CHECK("fdbm_gn_apply");
+  return 0;
+}

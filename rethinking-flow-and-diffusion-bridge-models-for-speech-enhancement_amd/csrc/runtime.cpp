@@ -1,0 +1,81 @@
+// runtime.cpp - error reporting and the recorded-program runner.
+#include <stdarg.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void fdbm_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* fdbm_last_error(void) { return g_err; }
+extern "C" int fdbm_version(void) { return 1; }
+
+#define P(i) ((void*)(intptr_t)o.iarg[i])
+#define CP(i) ((const void*)(intptr_t)o.iarg[i])
+#define FP(i) ((float*)(intptr_t)o.iarg[i])
+#define CFP(i) ((const float*)(intptr_t)o.iarg[i])
+#define I(i) ((int)o.iarg[i])
+
+// Argument order per opcode = the parameter order of the C entry point (pointers and
+// integers in iarg[], floats in farg[]), minus the trailing stream.
+extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* stream) {
+  for (int k = 0; k < n_ops; ++k) {
+    const fdbm_op& o = ops[k];
+    int rc = 0;
+    switch (o.opcode) {
+      case FDBM_OP_CONV:
+        rc = fdbm_conv_igemm((const fdbm_conv_args*)CP(0), stream);
+        break;
+      case FDBM_OP_GN_STATS:
+        rc = fdbm_gn_stats(FP(0), CP(1), I(2), CP(3), I(4), I(5), I(6), I(7), I(8), I(9), stream);
+        break;
+      case FDBM_OP_GN_FINALIZE:
+        rc = fdbm_gn_finalize(FP(0), CFP(1), I(2), I(3), I(4), o.iarg[5], o.farg[0], stream);
+        break;
+      case FDBM_OP_GN_APPLY:
+        rc = fdbm_gn_apply(P(0), CP(1), I(2), CP(3), I(4), CFP(5), CFP(6), CFP(7), I(8), I(9),
+                           I(10), I(11), I(12), stream);
+        break;
+      case FDBM_OP_RESAMPLE:
+        rc = fdbm_resample2x(P(0), P(1), CP(2), CFP(3), CFP(4), CFP(5), I(6), I(7), I(8), I(9),
+                             I(10), I(11), I(12), stream);
+        break;
+      case FDBM_OP_COMBINE:
+        rc = fdbm_combine(P(0), CP(1), CFP(2), CFP(3), CFP(4), o.iarg[5], I(6), I(7), stream);
+        break;
+      case FDBM_OP_ATTENTION:
+        rc = fdbm_attention(P(0), CP(1), I(2), I(3), I(4), I(5), stream);
+        break;
+      case FDBM_OP_STEM:
+        rc = fdbm_conv_stem(P(0), CFP(1), CFP(2), CFP(3), I(4), I(5), I(6), I(7), I(8), stream);
+        break;
+      case FDBM_OP_PACK:
+        rc = fdbm_pack_input(FP(0), CP(1), CP(2), I(3), I(4), I(5), I(6), stream);
+        break;
+      case FDBM_OP_UNPACK:
+        rc = fdbm_unpack_output(P(0), CFP(1), CFP(2), CFP(3), I(4), I(5), I(6), I(7), stream);
+        break;
+      case FDBM_OP_TEMB:
+        rc = fdbm_temb(FP(0), CFP(1), CFP(2), CFP(3), CFP(4), CFP(5), CFP(6), FP(7), I(8), I(9),
+                       stream);
+        break;
+      case FDBM_OP_DENSE:
+        rc = fdbm_dense_rows(FP(0), CFP(1), CFP(2), CFP(3), I(4), I(5), I(6), stream);
+        break;
+      case FDBM_OP_UPDATE:
+        rc = fdbm_bridge_update(P(0), CP(1), CP(2), CP(3), CFP(4), CFP(5), CFP(6), I(7), o.iarg[8],
+                                stream);
+        break;
+      default:
+        fdbm_set_error("fdbm_run_program: unknown opcode %d at op %d", o.opcode, k);
+        return 3;
+    }
+    if (rc) return rc;
+  }
+  return 0;
+}

@@ -1,0 +1,175 @@
+"""ctypes binding of csrc/libfdbm_hip.so (the C ABI declared in include/fdbm_hip.h).
+
+PyTorch is used here for device memory and streams only: every function takes
+torch CUDA(HIP) tensors, passes raw device pointers plus the CURRENT torch stream
+to the library, and returns torch tensors it allocated.  There is no fallback:
+if the shared library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+import torch
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libfdbm_hip.so")
+
+F32, BF16 = 0, 1
+MAX_SEG = 4
+_lib = None
+
+c_void_p, c_int, c_i64, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_float
+
+
+class ConvSeg(ctypes.Structure):
+    _fields_ = [("src", c_void_p), ("C", ctypes.c_int32), ("coff", ctypes.c_int32),
+                ("cin", ctypes.c_int32), ("taps", ctypes.c_int32)]
+
+
+class ConvArgs(ctypes.Structure):
+    _fields_ = [("seg", ConvSeg * MAX_SEG), ("nseg", ctypes.c_int32),
+                ("w", c_void_p), ("bias", c_void_p), ("tbias", c_void_p),
+                ("tbias_stride", ctypes.c_int32), ("res", c_void_p), ("scale", c_float),
+                ("out", c_void_p),
+                ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("Cout", ctypes.c_int32), ("CoutPad", ctypes.c_int32),
+                ("dt_in", ctypes.c_int32), ("dt_out", ctypes.c_int32)]
+
+
+class Op(ctypes.Structure):
+    _fields_ = [("opcode", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("iarg", c_i64 * 24), ("farg", c_float * 4)]
+
+
+OP_CONV, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_RESAMPLE, OP_COMBINE, OP_ATTENTION, \
+    OP_STEM, OP_PACK, OP_UNPACK, OP_TEMB, OP_DENSE, OP_UPDATE = range(1, 14)
+
+# name -> (argtypes without the trailing stream)
+_SIGS = {
+    "fdbm_bridge_update": [c_void_p] * 7 + [c_int, c_i64],
+    "fdbm_pc_predictor": [c_void_p] * 10 + [c_float, c_int, c_i64],
+    "fdbm_pc_corrector": [c_void_p] * 11 + [c_int, c_i64],
+    "fdbm_pack_input": [c_void_p] * 3 + [c_int] * 4,
+    "fdbm_unpack_output": [c_void_p] * 4 + [c_int] * 4,
+    "fdbm_temb": [c_void_p] * 8 + [c_int] * 2,
+    "fdbm_dense_rows": [c_void_p] * 4 + [c_int] * 3,
+    "fdbm_conv_stem": [c_void_p] * 4 + [c_int] * 5,
+    "fdbm_gn_stats": [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 5,
+    "fdbm_gn_finalize": [c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_float],
+    "fdbm_gn_apply": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5,
+    "fdbm_upfirdn2d": [c_void_p] * 3 + [c_int] * 14,
+    "fdbm_resample2x": [c_void_p] * 6 + [c_int] * 7,
+    "fdbm_conv_igemm": [ctypes.POINTER(ConvArgs)],
+    "fdbm_combine": [c_void_p] * 5 + [c_i64, c_int, c_int],
+    "fdbm_attention": [c_void_p, c_void_p] + [c_int] * 4,
+    "fdbm_stft": [c_void_p] * 3 + [c_int] * 8 + [c_float, c_float],
+    "fdbm_istft": [c_void_p] * 4 + [c_int] * 7 + [c_float, c_float],
+    "fdbm_spec_transform": [c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_int],
+    "fdbm_pad_spec": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int],
+    "fdbm_run_program": [ctypes.POINTER(Op), c_int],
+}
+EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc"])
+
+
+def lib():
+    """The loaded shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built "
+                "(run `python __graft_entry__.py build`). There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGS.items():
+            fn = getattr(L, name)
+            fn.argtypes = list(args) + [c_void_p]
+            fn.restype = c_int
+        L.fdbm_last_error.restype = ctypes.c_char_p
+        L.fdbm_last_error.argtypes = []
+        L.fdbm_version.restype = c_int
+        L.fdbm_conv_kc.argtypes = [c_int]
+        L.fdbm_conv_kc.restype = c_int
+        _lib = L
+    return _lib
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def call(name, *args):
+    L = lib()
+    rc = getattr(L, name)(*args, stream_ptr())
+    if rc != 0:
+        raise RuntimeError(f"{name} failed ({rc}): {L.fdbm_last_error().decode()}")
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise ValueError(f"unsupported activation dtype {dtype}")
+
+
+def conv_kc(code):
+    return lib().fdbm_conv_kc(code)
+
+
+def _dev_f32(w, device):
+    return w.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+# ---------------------------------------------------------------------------------
+# convenience wrappers (tensor in, tensor out) used by bridge.py and the tests
+# ---------------------------------------------------------------------------------
+def bridge_update(a, b, c, wa, wb, wc, out=None):
+    """(wa*a + wb*b) + wc*c on complex64 [B,...] tensors; weights are [B] float32."""
+    assert a.is_cuda and a.dtype == torch.complex64 and a.is_contiguous()
+    B = a.shape[0]
+    n = a[0].numel()
+    b = b.contiguous()
+    out = torch.empty_like(a) if out is None else out
+    dev = a.device
+    wa_d, wb_d = _dev_f32(wa, dev), _dev_f32(wb, dev)
+    wc_d = _dev_f32(wc, dev) if c is not None else None
+    if c is not None:
+        c = c.contiguous()
+    call("fdbm_bridge_update", ptr(out), ptr(a), ptr(b), ptr(c), ptr(wa_d), ptr(wb_d), ptr(wc_d), B, n)
+    return out
+
+
+def pc_predictor(x, s, y, z, wx, ws, wy, gd, dt):
+    dev = x.device
+    x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
+    ws_ = [_dev_f32(w, dev) for w in (wx, ws, wy, gd)]
+    call("fdbm_pc_predictor", ptr(x_new), ptr(x_mean), ptr(x.contiguous()), ptr(s.contiguous()),
+         ptr(y.contiguous()), ptr(z.contiguous()), *[ptr(w) for w in ws_], float(dt), x.shape[0], x[0].numel())
+    return x_new, x_mean
+
+
+def pc_corrector(x, s, y, noise, a, b, den, step, nscale):
+    dev = x.device
+    x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
+    ws_ = [_dev_f32(w, dev) for w in (a, b, den, step, nscale)]
+    call("fdbm_pc_corrector", ptr(x_new), ptr(x_mean), ptr(x.contiguous()), ptr(s.contiguous()),
+         ptr(y.contiguous()), ptr(noise.contiguous()), *[ptr(w) for w in ws_], x.shape[0], x[0].numel())
+    return x_new, x_mean
+
+
+def upfirdn2d(inp, kernel, up=1, down=1, pad=(0, 0)):
+    """Same call shape as the reference's python wrapper (op/upfirdn2d.py:148-159) for NCHW
+    float32 tensors: runs fdbm_upfirdn2d on the [B*C, H, W, 1] view."""
+    assert inp.is_cuda and inp.dtype == torch.float32
+    B, C, H, W = inp.shape
+    kh, kw = kernel.shape
+    k = _dev_f32(kernel, inp.device)
+    out_h = (H * up + pad[0] + pad[1] - kh) // down + 1
+    out_w = (W * up + pad[0] + pad[1] - kw) // down + 1
+    out = torch.empty(B, C, out_h, out_w, device=inp.device, dtype=torch.float32)
+    call("fdbm_upfirdn2d", ptr(out), ptr(inp.contiguous()), ptr(k), B * C, H, W, 1, kh, kw,
+         up, up, down, down, pad[0], pad[1], pad[0], pad[1])
+    return out

@@ -1,0 +1,438 @@
+"""Compiles an ``arch.Spec`` + weights into a recorded launch program for one input shape.
+
+The reference evaluates the backbone as ~1.1k framework ops per forward
+(fdbm/backbones/ncsnpp_v2.py:241-401).  Here the forward for a given
+(B, F, T, dtype) is a FIXED list of a few hundred calls into libfdbm_hip.so,
+recorded once (``fdbm_op`` array, include/fdbm_hip.h) and replayed with one
+``fdbm_run_program`` call - and, by ``engine.SamplerGraph``, captured together
+with the sampler's state updates into a HIP graph.
+
+Data layout in HBM: activations NHWC ``[B][H=freq][W=time][C]`` (C contiguous) in
+the model dtype (bf16 throughput mode / f32 parity mode); the 4-channel input and
+output pyramids, GroupNorm statistics, biases and the time embedding stay f32;
+conv weights are pre-packed per k-step as ``[kstep][CoutPad][128 bytes]``.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import hip
+from .arch import Spec, IN_CH, OUT_CH, IMAGE_SIZE, gn_groups
+
+_INV_SQRT2 = float(1.0 / np.sqrt(2.0))
+
+
+# ---------------------------------------------------------------------------------
+# analytic work count (no device needed)
+# ---------------------------------------------------------------------------------
+def count_macs(spec, F=256, T=256):
+    """Multiply-accumulates of one forward for one sample (conv + NIN + attention + linear)."""
+    macs = 0
+    nf = spec.nf
+    macs += 2 * nf * 4 * nf + 4 * nf * 4 * nf           # temb MLP
+    H, W = F, T
+    macs += H * W * nf * IN_CH * 9                       # stem
+
+    def res(in_ch, out_ch, h, w, up=False, down=False):
+        if up:
+            h, w = 2 * h, 2 * w
+        if down:
+            h, w = h // 2, w // 2
+        m = h * w * (in_ch * out_ch * 9 + out_ch * out_ch * 9) + 4 * nf * out_ch
+        if in_ch != out_ch or up or down:
+            m += h * w * in_ch * out_ch
+        return m
+
+    def attn(c, h, w):
+        n = h * w
+        return 4 * n * c * c + 2 * n * n * c
+
+    hs_c = [nf]
+    in_ch = nf
+    for lvl in range(spec.num_resolutions):
+        for _ in range(spec.num_res_blocks):
+            out_ch = nf * spec.ch_mult[lvl]
+            macs += res(in_ch, out_ch, H, W)
+            in_ch = out_ch
+            if H in spec.attn_resolutions:
+                macs += attn(in_ch, H, W)
+            hs_c.append(in_ch)
+        if lvl != spec.num_resolutions - 1:
+            macs += res(in_ch, in_ch, H, W, down=True)
+            H, W = H // 2, W // 2
+            macs += H * W * IN_CH * in_ch                # Combine conv1x1
+            hs_c.append(in_ch)
+    macs += res(in_ch, in_ch, H, W) * 2 + attn(in_ch, H, W)
+    for lvl in reversed(range(spec.num_resolutions)):
+        for _ in range(spec.num_res_blocks + 1):
+            out_ch = nf * spec.ch_mult[lvl]
+            macs += res(in_ch + hs_c.pop(), out_ch, H, W)
+            in_ch = out_ch
+        if H in spec.attn_resolutions:
+            macs += attn(in_ch, H, W)
+        macs += H * W * in_ch * IN_CH * 9                # pyramid head
+        if lvl != 0:
+            macs += res(in_ch, in_ch, H, W, up=True)
+            H, W = 2 * H, 2 * W
+    macs += H * W * IN_CH * OUT_CH                       # output layer
+    return macs
+
+
+# ---------------------------------------------------------------------------------
+# device-side weights
+# ---------------------------------------------------------------------------------
+def pack_conv_weight(segments, kc, dtype, device):
+    """segments: list of (W [Cout, cin, kh, kw] float32 tensor, taps) in K order ->
+    packed [nk, CoutPad, kc] tensor of `dtype` (zero padded), CoutPad."""
+    cout = segments[0][0].shape[0]
+    cout_pad = ((cout + 127) // 128) * 128
+    blocks = []
+    for W, taps in segments:
+        W = W.to(device=device, dtype=torch.float32)
+        assert W.shape[0] == cout
+        cin = W.shape[1]
+        Wt = W.reshape(cout, cin, -1)                    # [Cout, cin, taps]
+        assert Wt.shape[2] == taps
+        nch = (cin + kc - 1) // kc
+        Wp = torch.zeros(cout, nch * kc, taps, device=device)
+        Wp[:, :cin] = Wt
+        Wp = Wp.reshape(cout, nch, kc, taps).permute(3, 1, 0, 2).reshape(taps * nch, cout, kc)
+        blocks.append(Wp)
+    Wk = torch.cat(blocks, dim=0)
+    out = torch.zeros(Wk.shape[0], cout_pad, kc, device=device, dtype=dtype)
+    out[:, :cout] = Wk.to(dtype)
+    return out.contiguous(), cout_pad
+
+
+class Act:
+    """An NHWC activation living in a pooled buffer."""
+    __slots__ = ("t", "B", "H", "W", "C", "dtype")
+
+    def __init__(self, t, B, H, W, C, dtype):
+        self.t, self.B, self.H, self.W, self.C, self.dtype = t, B, H, W, C, dtype
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+    @property
+    def M(self):
+        return self.B * self.H * self.W
+
+
+class Pool:
+    """Size-keyed free list of device buffers; reuse is safe because all ops of a
+    program run in order on one stream (and keeps the working set hot in the 256 MiB
+    Infinity Cache at small batch)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.free = {}
+        self.all = []
+
+    def get(self, nbytes):
+        nbytes = (nbytes + 255) // 256 * 256
+        lst = self.free.get(nbytes)
+        if lst:
+            return lst.pop()
+        t = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self.all.append(t)
+        return t
+
+    def put(self, t):
+        self.free.setdefault(t.numel(), []).append(t)
+
+    def total_bytes(self):
+        return sum(t.numel() for t in self.all)
+
+
+class Program:
+    """The recorded forward for one (B, F, T)."""
+
+    def __init__(self, net, B, F, T):
+        spec = net.spec
+        assert F in (IMAGE_SIZE, IMAGE_SIZE + 1), f"F must be 256 or 257 (got {F})"
+        down = 2 ** (spec.num_resolutions - 1)
+        assert T % down == 0, f"T={T} must be a multiple of {down} (pad_spec pads to 64)"
+        self.net, self.B, self.F, self.T = net, B, F, T
+        self.dev = net.device
+        self.dt = net.dtype
+        self.dtc = hip.dt_code(net.dtype)
+        self.esize = 2 if net.dtype == torch.bfloat16 else 4
+        self.pool = Pool(self.dev)
+        self.ops = []          # (opcode, iargs, fargs)
+        self.keep = []         # ctypes structs / tensors that must outlive the program
+        self.macs = 0
+        dev = self.dev
+        self.x_in = torch.zeros(B, 1, F, T, dtype=torch.complex64, device=dev)
+        self.y_in = torch.zeros(B, 1, F, T, dtype=torch.complex64, device=dev)
+        self.t_in = torch.ones(B, dtype=torch.float32, device=dev)
+        self.s_out = torch.zeros(B, 1, F, T, dtype=torch.complex64, device=dev)
+        self._build()
+        self._finalize()
+
+    # ---- buffers ---------------------------------------------------------------------
+    def new_act(self, H, W, C, dtype=None):
+        dtype = dtype or self.dt
+        es = 2 if dtype == torch.bfloat16 else 4
+        raw = self.pool.get(self.B * H * W * C * es)
+        return Act(raw, self.B, H, W, C, dtype)
+
+    def free_act(self, a):
+        self.pool.put(a.t)
+
+    def new_f32(self, n):
+        return self.pool.get(n * 4)
+
+    # ---- op recording ------------------------------------------------------------------
+    def emit(self, opcode, iargs, fargs=()):
+        self.ops.append((opcode, [int(v) for v in iargs], [float(v) for v in fargs]))
+
+    def gn_stats(self, srcs, G):
+        """srcs: list of 1 or 2 Acts (virtual concat) -> mean_rstd buffer [B][G][2]."""
+        a0 = srcs[0]
+        a1 = srcs[1] if len(srcs) > 1 else None
+        HW = a0.H * a0.W
+        C = a0.C + (a1.C if a1 else 0)
+        nsplit = max(1, min(HW, 256, (HW * C) // 32768))
+        partial = self.new_f32(self.B * nsplit * G * 2)
+        mr = self.new_f32(self.B * G * 2)
+        self.emit(hip.OP_GN_STATS, [partial.data_ptr(), a0.ptr, a0.C, a1.ptr if a1 else 0,
+                                    a1.C if a1 else 0, self.B, HW, G, nsplit, hip.dt_code(a0.dtype)])
+        self.emit(hip.OP_GN_FINALIZE, [mr.data_ptr(), partial.data_ptr(), self.B, nsplit, G,
+                                       HW * (C // G)], [1e-6])
+        self.pool.put(partial)
+        return mr
+
+    def gn_apply(self, srcs, mr, gamma, beta, G, silu):
+        a0 = srcs[0]
+        a1 = srcs[1] if len(srcs) > 1 else None
+        C = a0.C + (a1.C if a1 else 0)
+        out = self.new_act(a0.H, a0.W, C)
+        self.emit(hip.OP_GN_APPLY, [out.ptr, a0.ptr, a0.C, a1.ptr if a1 else 0, a1.C if a1 else 0,
+                                    mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), self.B,
+                                    a0.H * a0.W, G, 1 if silu else 0, self.dtc])
+        return out
+
+    def conv(self, segs, wpack, cout_pad, cout, bias, out_dtype=None, tbias=None, tb_stride=0,
+             res=None, scale=1.0):
+        """segs: list of (Act, coff, cin, taps)."""
+        a0 = segs[0][0]
+        out = self.new_act(a0.H, a0.W, cout, out_dtype or self.dt)
+        ca = hip.ConvArgs()
+        for i, (a, coff, cin, taps) in enumerate(segs):
+            assert a.H == a0.H and a.W == a0.W and a.dtype == a0.dtype
+            ca.seg[i].src, ca.seg[i].C, ca.seg[i].coff, ca.seg[i].cin, ca.seg[i].taps = a.ptr, a.C, coff, cin, taps
+            self.macs += a0.H * a0.W * cout * cin * taps
+        ca.nseg = len(segs)
+        ca.w = wpack.data_ptr()
+        ca.bias = bias.data_ptr() if bias is not None else 0
+        ca.tbias = tbias if tbias else 0
+        ca.tbias_stride = tb_stride
+        ca.res = res.ptr if res is not None else 0
+        ca.scale = scale
+        ca.out = out.ptr
+        ca.B, ca.H, ca.W, ca.Cout, ca.CoutPad = self.B, a0.H, a0.W, cout, cout_pad
+        ca.dt_in = hip.dt_code(a0.dtype)
+        ca.dt_out = hip.dt_code(out.dtype)
+        self.keep.append(ca)
+        self.emit(hip.OP_CONV, [ctypes.addressof(ca)])
+        return out
+
+    def resample(self, a, up, mr=None, gamma=None, beta=None, G=0, want_plain=True):
+        OH, OW = (2 * a.H, 2 * a.W) if up else (a.H // 2, a.W // 2)
+        plain = self.new_act(OH, OW, a.C, a.dtype) if want_plain else None
+        act = self.new_act(OH, OW, a.C, a.dtype) if mr is not None else None
+        self.emit(hip.OP_RESAMPLE, [plain.ptr if plain else 0, act.ptr if act else 0, a.ptr,
+                                    mr.data_ptr() if mr is not None else 0,
+                                    gamma.data_ptr() if gamma is not None else 0,
+                                    beta.data_ptr() if beta is not None else 0,
+                                    self.B, a.H, a.W, a.C, G, 1 if up else 0, hip.dt_code(a.dtype)])
+        return plain, act
+
+    # ---- blocks ------------------------------------------------------------------------
+    def resblock(self, mod, srcs):
+        """srcs: [h] or [h, skip]; returns the block output Act.  Does not free srcs."""
+        W = self.net.w[mod.idx]
+        in_ch, out_ch = mod.in_ch, mod.out_ch
+        G0, G1 = gn_groups(in_ch), gn_groups(out_ch)
+        mr0 = self.gn_stats(srcs, G0)
+        xr = None
+        if mod.up or mod.down:
+            assert len(srcs) == 1
+            xr, a0 = self.resample(srcs[0], mod.up, mr0, W["gn0_w"], W["gn0_b"], G0)
+            short_srcs = [xr]
+        else:
+            a0 = self.gn_apply(srcs, mr0, W["gn0_w"], W["gn0_b"], G0, True)
+            short_srcs = srcs
+        self.pool.put(mr0)
+        tb = self.net.dense_out_ptr(self, mod.idx)
+        h1 = self.conv([(a0, 0, in_ch, 9)], W["conv0"], W["conv0_pad"], out_ch, W["conv0_b"],
+                       tbias=tb, tb_stride=self.net.dense_rows)
+        self.free_act(a0)
+        mr1 = self.gn_stats([h1], G1)
+        a1 = self.gn_apply([h1], mr1, W["gn1_w"], W["gn1_b"], G1, True)
+        self.pool.put(mr1)
+        self.free_act(h1)
+        segs = [(a1, 0, out_ch, 9)]
+        res = None
+        if W["has_conv2"]:
+            for s in short_srcs:
+                segs.append((s, 0, s.C, 1))
+        else:
+            assert len(short_srcs) == 1 and short_srcs[0].C == out_ch
+            res = short_srcs[0]
+        out = self.conv(segs, W["conv1"], W["conv1_pad"], out_ch, W["conv1_b"], res=res, scale=_INV_SQRT2)
+        self.free_act(a1)
+        if xr is not None:
+            self.free_act(xr)
+        return out
+
+    def attnblock(self, mod, x):
+        W = self.net.w[mod.idx]
+        C = mod.in_ch
+        G = gn_groups(C)
+        mr = self.gn_stats([x], G)
+        a = self.gn_apply([x], mr, W["gn_w"], W["gn_b"], G, False)
+        self.pool.put(mr)
+        qkv = self.conv([(a, 0, C, 1)], W["qkv"], W["qkv_pad"], 3 * C, W["qkv_b"])
+        self.free_act(a)
+        N = x.H * x.W
+        att = self.new_act(x.H, x.W, C)
+        self.emit(hip.OP_ATTENTION, [att.ptr, qkv.ptr, self.B, N, C, self.dtc])
+        self.macs += 2 * N * N * C
+        self.free_act(qkv)
+        out = self.conv([(att, 0, C, 1)], W["proj"], W["proj_pad"], C, W["proj_b"], res=x, scale=_INV_SQRT2)
+        self.free_act(att)
+        return out
+
+    # ---- whole network (module order of ncsnpp_v2.py:241-401) ------------------------------
+    def _build(self):
+        net, spec = self.net, self.net.spec
+        B, F, T = self.B, self.F, self.T
+        Fn = IMAGE_SIZE
+        nf = spec.nf
+        mods = spec.mods
+        mi = [3]
+
+        def nxt():
+            m = mods[mi[0]]
+            mi[0] += 1
+            return m
+
+        # time embedding + all Dense_0 rows
+        self.temb_act = self.new_f32(B * 4 * nf)
+        temb_scratch = self.new_f32(B * 4 * nf)
+        self.dense_out = self.new_f32(B * net.dense_rows)
+        self.emit(hip.OP_TEMB, [self.temb_act.data_ptr(), self.t_in.data_ptr(), net.fourier_w.data_ptr(),
+                                net.lin1_w.data_ptr(), net.lin1_b.data_ptr(), net.lin2_w.data_ptr(),
+                                net.lin2_b.data_ptr(), temb_scratch.data_ptr(), B, nf])
+        self.emit(hip.OP_DENSE, [self.dense_out.data_ptr(), self.temb_act.data_ptr(), net.dense_w.data_ptr(),
+                                 net.dense_b.data_ptr(), B, net.dense_rows, 4 * nf])
+        self.macs += 2 * nf * 4 * nf + 4 * nf * 4 * nf + net.dense_rows * 4 * nf
+
+        # input packing + stem
+        inp = self.new_act(Fn, T, IN_CH, torch.float32)
+        self.op_pack = len(self.ops)
+        self.emit(hip.OP_PACK, [inp.ptr, self.x_in.data_ptr(), self.y_in.data_ptr(), B, F, Fn, T])
+        stem = nxt()
+        h = self.new_act(Fn, T, nf)
+        sw = net.w[stem.idx]
+        self.emit(hip.OP_STEM, [h.ptr, inp.ptr, sw["w"].data_ptr(), sw["b"].data_ptr(), B, Fn, T, nf, self.dtc])
+        self.macs += Fn * T * nf * IN_CH * 9
+        hs = [h]
+        pyr_in = inp
+
+        nres = spec.num_resolutions
+        for lvl in range(nres):
+            for _ in range(spec.num_res_blocks):
+                h = self.resblock(nxt(), [hs[-1]])
+                if h.H in spec.attn_resolutions:
+                    h2 = self.attnblock(nxt(), h)
+                    self.free_act(h)
+                    h = h2
+                hs.append(h)
+            if lvl != nres - 1:
+                hd = self.resblock(nxt(), [hs[-1]])
+                comb = nxt()
+                pyr_down, _ = self.resample(pyr_in, False)
+                if pyr_in is not inp:
+                    self.free_act(pyr_in)
+                pyr_in = pyr_down
+                cw = net.w[comb.idx]
+                self.emit(hip.OP_COMBINE, [hd.ptr, hd.ptr, pyr_in.ptr, cw["w"].data_ptr(), cw["b"].data_ptr(),
+                                           hd.M, hd.C, self.dtc])
+                self.macs += hd.H * hd.W * IN_CH * hd.C
+                hs.append(hd)
+        if pyr_in is not inp:
+            self.free_act(pyr_in)
+        self.free_act(inp)
+
+        h = hs[-1]
+        h2 = self.resblock(nxt(), [h])          # h stays alive: it is on the skip stack
+        h3 = self.attnblock(nxt(), h2)
+        self.free_act(h2)
+        h = self.resblock(nxt(), [h3])
+        self.free_act(h3)
+
+        pyramid = None
+        for lvl in reversed(range(nres)):
+            for _ in range(spec.num_res_blocks + 1):
+                skip = hs.pop()
+                hn = self.resblock(nxt(), [h, skip])
+                self.free_act(h)
+                self.free_act(skip)
+                h = hn
+            if h.H in spec.attn_resolutions:
+                hn = self.attnblock(nxt(), h)
+                self.free_act(h)
+                h = hn
+            gnm, head = nxt(), nxt()
+            G = gn_groups(h.C)
+            gw, hw = net.w[gnm.idx], net.w[head.idx]
+            mr = self.gn_stats([h], G)
+            a = self.gn_apply([h], mr, gw["w"], gw["b"], G, True)
+            self.pool.put(mr)
+            up_pyr = None
+            if pyramid is not None:
+                up_pyr, _ = self.resample(pyramid, True)
+                self.free_act(pyramid)
+            pyramid = self.conv([(a, 0, h.C, 9)], hw["w"], hw["pad"], IN_CH, hw["b"],
+                                out_dtype=torch.float32, res=up_pyr, scale=1.0)
+            self.free_act(a)
+            if up_pyr is not None:
+                self.free_act(up_pyr)
+            if lvl != 0:
+                hn = self.resblock(nxt(), [h])
+                self.free_act(h)
+                h = hn
+        assert not hs and mi[0] == len(mods)
+        self.free_act(h)
+        ow = net.w[-1]
+        self.emit(hip.OP_UNPACK, [self.s_out.data_ptr(), pyramid.ptr, ow["w"].data_ptr(), ow["b"].data_ptr(),
+                                  B, F, Fn, T])
+        self.macs += Fn * T * IN_CH * OUT_CH
+        self.macs_per_sample = self.macs       # self.macs was accumulated per sample (H*W, not B*H*W)
+
+    def _finalize(self):
+        n = len(self.ops)
+        arr = (hip.Op * n)()
+        for i, (opc, ia, fa) in enumerate(self.ops):
+            arr[i].opcode = opc
+            for j, v in enumerate(ia):
+                arr[i].iarg[j] = v
+            for j, v in enumerate(fa):
+                arr[i].farg[j] = v
+        self.op_array = arr
+        self.n_ops = n
+
+    # ---- execution ---------------------------------------------------------------------
+    def run(self):
+        """Enqueue the whole forward on the current stream (reads x_in/y_in/t_in, writes s_out)."""
+        hip.call("fdbm_run_program", self.op_array, self.n_ops)
+
+    def run_range(self, lo, hi):
+        sub = ctypes.cast(ctypes.byref(self.op_array, lo * ctypes.sizeof(hip.Op)), ctypes.POINTER(hip.Op))
+        hip.call("fdbm_run_program", sub, hi - lo)

@@ -1,0 +1,339 @@
+"""GPU parity of every C-ABI kernel against the CPU oracle / plain torch fp32 on the host.
+
+All calls go through the C ABI (ctypes -> libfdbm_hip.so).  Tolerances are written
+next to each check: bit-exact for the sampler update; fp32 kernels within a few ulp-sums
+of the fp32 reference; bf16 kernels within bf16 rounding of inputs/outputs.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import fdbm_amd  # noqa: F401
+from fdbm_amd import hip
+from fdbm_amd.program import pack_conv_weight
+from oracle import ncsnpp as onet
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def nhwc(x, dtype=torch.float32):
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV, dtype)
+
+
+def nchw(x):
+    return x.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def crnd(*shape, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.view_as_complex(torch.randn(*shape, 2, generator=g))
+
+
+# ---------------------------------------------------------------------------------------
+def test_bridge_update_bit_exact():
+    for B, shape in ((1, (1, 257, 64)), (3, (1, 257, 20)), (2, (1, 5, 3))):
+        a, b, c = (crnd(B, *shape, seed=s) for s in (1, 2, 3))
+        wa = torch.tensor([1794.7899, 0.7, -2.5][:B])
+        wb = torch.tensor([0.0333, 1.3, 0.25][:B])
+        wc = torch.tensor([-1793.82, 0.1, 3.0][:B])
+        e = lambda w: w[:, None, None, None]
+        ref = e(wa) * a + e(wb) * b + e(wc) * c
+        out = hip.bridge_update(a.to(DEV), b.to(DEV), c.to(DEV), wa, wb, wc).cpu()
+        assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref))
+        ref2 = e(wa) * a + e(wb) * b
+        out2 = hip.bridge_update(a.to(DEV), b.to(DEV), None, wa, wb, None).cpu()
+        assert torch.equal(torch.view_as_real(out2), torch.view_as_real(ref2))
+    # in place
+    a, b, c = (crnd(2, 1, 257, 64, seed=s).to(DEV) for s in (4, 5, 6))
+    w = torch.tensor([0.5, 2.0])
+    ref = hip.bridge_update(a, b, c, w, w, w)
+    hip.bridge_update(a, b, c, w, w, w, out=a)
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(ref))
+
+
+def test_pc_moves():
+    B = 2
+    x, s, y, z = (crnd(B, 1, 257, 16, seed=i) for i in range(4))
+    wx, ws, wy, gd = (torch.tensor(v) for v in ([1.5, -0.3], [-2.0, 0.4], [0.7, 0.2], [1.0, 0.8]))
+    dt = -0.0312
+    e = lambda w: w[:, None, None, None]
+    drift = e(wx) * x + e(ws) * s + e(wy) * y
+    xm_ref = x + drift * dt
+    xn_ref = xm_ref + e(gd) * math.sqrt(-dt) * z
+    xn, xm = hip.pc_predictor(x.to(DEV), s.to(DEV), y.to(DEV), z.to(DEV), wx, ws, wy, gd, dt)
+    assert (xm.cpu() - xm_ref).abs().max() < 1e-6
+    assert (xn.cpu() - xn_ref).abs().max() < 1e-6
+    a, b, den, step = (torch.tensor(v) for v in ([0.3, 0.6], [0.7, 0.4], [0.2, 0.05], [0.01, 0.002]))
+    score = -(x - (e(a) * s + e(b) * y)) / e(den)
+    xm_ref = x + e(step) * score
+    xn_ref = xm_ref + z * e(torch.sqrt(step * 2))
+    xn, xm = hip.pc_corrector(x.to(DEV), s.to(DEV), y.to(DEV), z.to(DEV), a, b, den, step, torch.sqrt(step * 2))
+    assert (xm.cpu() - xm_ref).abs().max() < 2e-6
+    assert (xn.cpu() - xn_ref).abs().max() < 2e-6
+
+
+def test_upfirdn2d_generic(golden):
+    g = golden("ops")
+    x = torch.from_numpy(g["resample_x"])
+    k = torch.from_numpy(g["ufd_kernel"])
+    for key, kw in (("ufd_up2_down1", dict(up=2, down=1, pad=(2, 1))), ("ufd_up1_down2", dict(up=1, down=2, pad=(1, 1))),
+                    ("ufd_up2_down3_negpad", dict(up=2, down=3, pad=(-1, 2)))):
+        out = hip.upfirdn2d(x.to(DEV), k, **kw).cpu()
+        assert out.shape == g[key].shape
+        assert (out - torch.from_numpy(g[key])).abs().max() < 1e-5, key
+    k4 = onet.fir_kernel_2d((1, 3, 3, 1), gain=4.0)
+    out = hip.upfirdn2d(x.to(DEV), k4, up=2, pad=(2, 1)).cpu()
+    assert (out - torch.from_numpy(g["upsample"])).abs().max() < 1e-6
+    out = hip.upfirdn2d(x.to(DEV), onet.fir_kernel_2d(), down=2, pad=(1, 1)).cpu()
+    assert (out - torch.from_numpy(g["downsample"])).abs().max() < 1e-6
+
+
+def _gn_mr(x_list, G):
+    """run gn_stats + finalize on NHWC device tensors -> mean_rstd [B][G][2]"""
+    a0 = x_list[0]
+    a1 = x_list[1] if len(x_list) > 1 else None
+    B, H, W, C0 = a0.shape
+    C1 = a1.shape[3] if a1 is not None else 0
+    HW = H * W
+    nsplit = max(1, min(HW, 7))
+    partial = torch.empty(B * nsplit * G * 2, device=DEV)
+    mr = torch.empty(B, G, 2, device=DEV)
+    dtc = hip.dt_code(a0.dtype)
+    hip.call("fdbm_gn_stats", hip.ptr(partial), hip.ptr(a0), C0, hip.ptr(a1), C1, B, HW, G, nsplit, dtc)
+    hip.call("fdbm_gn_finalize", hip.ptr(mr), hip.ptr(partial), B, nsplit, G, HW * ((C0 + C1) // G), 1e-6)
+    return mr
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-5), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("C0,C1,G", [(32, 0, 8), (128, 64, 32), (96, 0, 24), (256, 128, 32)])
+def test_groupnorm(dtype, tol, C0, C1, G):
+    B, H, W = 2, 8, 12
+    x0 = rnd(B, C0, H, W, seed=1) * 2 + 0.5
+    x1 = rnd(B, C1, H, W, seed=2) if C1 else None
+    d0 = nhwc(x0, dtype)
+    d1 = nhwc(x1, dtype) if C1 else None
+    # reference on what the device actually sees (bf16-rounded inputs)
+    xc = torch.cat([nchw(d0)] + ([nchw(d1)] if C1 else []), 1)
+    gamma, beta = rnd(C0 + C1, seed=3) * 0.1 + 1, rnd(C0 + C1, seed=4) * 0.1
+    ref = F.silu(F.group_norm(xc, G, gamma, beta, eps=1e-6))
+    mr = _gn_mr([d0] + ([d1] if C1 else []), G)
+    xr = xc.reshape(B, G, -1)
+    assert (mr[:, :, 0].cpu() - xr.mean(-1)).abs().max() < 1e-5
+    rstd = 1 / torch.sqrt(xr.var(-1, unbiased=False) + 1e-6)
+    assert ((mr[:, :, 1].cpu() - rstd) / rstd).abs().max() < 1e-5
+    out = torch.empty(B, H, W, C0 + C1, device=DEV, dtype=dtype)
+    hip.call("fdbm_gn_apply", hip.ptr(out), hip.ptr(d0), C0, hip.ptr(d1), C1, hip.ptr(mr), hip.ptr(gamma.to(DEV)),
+             hip.ptr(beta.to(DEV)), B, H * W, G, 1, hip.dt_code(dtype))
+    assert (nchw(out) - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("up", [False, True])
+def test_resample2x(dtype, tol, up):
+    B, C, H, W, G = 2, 32, 8, 12, 8
+    x = rnd(B, C, H, W, seed=5)
+    d = nhwc(x, dtype)
+    xs = nchw(d)
+    gamma, beta = rnd(C, seed=3) * 0.1 + 1, rnd(C, seed=4) * 0.1
+    fn = onet.upsample_2d if up else onet.downsample_2d
+    ref_plain = fn(xs)
+    ref_act = fn(F.silu(F.group_norm(xs, G, gamma, beta, eps=1e-6)))
+    mr = _gn_mr([d], G)
+    OH, OW = (2 * H, 2 * W) if up else (H // 2, W // 2)
+    o_plain = torch.empty(B, OH, OW, C, device=DEV, dtype=dtype)
+    o_act = torch.empty_like(o_plain)
+    hip.call("fdbm_resample2x", hip.ptr(o_plain), hip.ptr(o_act), hip.ptr(d), hip.ptr(mr), hip.ptr(gamma.to(DEV)),
+             hip.ptr(beta.to(DEV)), B, H, W, C, G, int(up), hip.dt_code(dtype))
+    assert (nchw(o_plain) - ref_plain).abs().max() < tol
+    assert (nchw(o_act) - ref_act).abs().max() < tol
+    # plain only, 4-channel f32 pyramid flavour
+    if dtype == torch.float32:
+        p = rnd(B, 4, H, W, seed=6)
+        dp = nhwc(p)
+        o = torch.empty(B, OH, OW, 4, device=DEV)
+        hip.call("fdbm_resample2x", hip.ptr(o), 0, hip.ptr(dp), 0, 0, 0, B, H, W, 4, 0, int(up), hip.F32)
+        assert (nchw(o) - fn(p)).abs().max() < 1e-6
+
+
+def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=None, scale=1.0):
+    """segs_nchw: list of (x NCHW cpu tensor, taps); weights: list of W [Cout, cin, k, k] per seg."""
+    out_dtype = out_dtype or dtype
+    kc = hip.conv_kc(hip.dt_code(dtype))
+    wpack, cpad = pack_conv_weight([(w, t) for w, (_, t) in zip(weights, segs_nchw)], kc, dtype, DEV)
+    B, _, H, W = segs_nchw[0][0].shape
+    cout = weights[0].shape[0]
+    ca = hip.ConvArgs()
+    keep = []
+    for i, (x, taps) in enumerate(segs_nchw):
+        d = nhwc(x, dtype)
+        keep.append(d)
+        ca.seg[i].src, ca.seg[i].C, ca.seg[i].coff, ca.seg[i].cin, ca.seg[i].taps = d.data_ptr(), d.shape[3], 0, d.shape[3], taps
+    ca.nseg = len(segs_nchw)
+    ca.w = wpack.data_ptr()
+    bd = bias.to(DEV) if bias is not None else None
+    ca.bias = hip.ptr(bd)
+    tb = tbias.to(DEV).contiguous() if tbias is not None else None
+    ca.tbias = hip.ptr(tb)
+    ca.tbias_stride = tb.shape[1] if tb is not None else 0
+    rd = nhwc(res, out_dtype) if res is not None else None
+    ca.res = hip.ptr(rd)
+    ca.scale = scale
+    out = torch.full((B, H, W, cout), float("nan"), device=DEV, dtype=out_dtype)
+    ca.out = out.data_ptr()
+    ca.B, ca.H, ca.W, ca.Cout, ca.CoutPad = B, H, W, cout, cpad
+    ca.dt_in, ca.dt_out = hip.dt_code(dtype), hip.dt_code(out_dtype)
+    hip.call("fdbm_conv_igemm", ca)
+    torch.cuda.synchronize()
+    return nchw(out), keep, rd
+
+
+CONV_CASES = [
+    # name, B, H, W, cins(list), cout, taps, extra
+    ("3x3_128", 2, 16, 24, [128], 128, 9, {}),
+    ("3x3_small_m", 1, 4, 4, [256], 256, 9, {}),
+    ("3x3_concat", 1, 8, 12, [256, 128], 128, 9, {}),
+    ("3x3_nf96", 1, 8, 8, [96], 192, 9, {}),
+    ("1x1_qkv", 2, 16, 4, [64], 192, 1, {}),
+    ("head_c4", 1, 16, 16, [128], 4, 9, dict(head=True)),
+    ("res_tbias", 2, 8, 8, [64], 64, 9, dict(res=True, tbias=True)),
+    ("shortcut", 1, 8, 8, [128], 256, 9, dict(shortcut=[256, 128])),
+    ("ragged_w", 1, 6, 10, [32], 32, 9, {}),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_igemm(case, dtype):
+    name, B, H, W, cins, cout, taps, extra = case
+    k = 3 if taps == 9 else 1
+    xs = [rnd(B, c, H, W, seed=10 + i) for i, c in enumerate(cins)]
+    ws = [rnd(cout, c, k, k, seed=20 + i) / math.sqrt(sum(cins) * taps) for i, c in enumerate(cins)]
+    bias = rnd(cout, seed=30) * 0.1
+    q = lambda t: t.to(dtype).float()        # what the device sees
+    ref = F.conv2d(torch.cat([q(x) for x in xs], 1), torch.cat([q(w) for w in ws], 1), bias, padding=k // 2)
+    segs = [(x, taps) for x in xs]
+    weights = list(ws)
+    kw = {}
+    if extra.get("shortcut"):
+        sx = [rnd(B, c, H, W, seed=40 + i) for i, c in enumerate(extra["shortcut"])]
+        sw = [rnd(cout, c, 1, 1, seed=50 + i) / math.sqrt(sum(extra["shortcut"])) for i, c in enumerate(extra["shortcut"])]
+        ref = ref + F.conv2d(torch.cat([q(x) for x in sx], 1), torch.cat([q(w) for w in sw], 1))
+        segs += [(x, 1) for x in sx]
+        weights += sw
+    if extra.get("tbias"):
+        tb = rnd(B, cout + 8, seed=60)
+        ref = ref + tb[:, :cout, None, None]
+        kw["tbias"] = tb
+    out_dtype = dtype
+    if extra.get("res"):
+        r = rnd(B, cout, H, W, seed=70)
+        ref = (ref + q(r)) / math.sqrt(2.0)
+        kw.update(res=r, scale=1 / math.sqrt(2.0))
+    if extra.get("head"):
+        out_dtype = torch.float32
+        r = rnd(B, cout, H, W, seed=71)
+        ref = ref + r
+        kw.update(res=r, scale=1.0)
+    out, _, _ = run_conv(segs, weights, bias, dtype, out_dtype=out_dtype, **kw)
+    assert not torch.isnan(out).any()
+    err = (out - ref).abs().max().item()
+    tol = 2e-5 if dtype == torch.float32 else (2e-2 if out_dtype == torch.bfloat16 else 2e-3)
+    assert err < tol, (name, err)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("N,C", [(64, 32), (256, 256), (40, 96), (16, 192)])
+def test_attention(dtype, tol, N, C):
+    B = 2
+    qkv = rnd(B, N, 3 * C, seed=80).to(dtype)
+    qf = qkv.float()
+    q, k, v = qf[..., :C], qf[..., C:2 * C], qf[..., 2 * C:]
+    w = torch.softmax(torch.einsum("bic,bjc->bij", q, k) * (C ** -0.5), dim=-1)
+    ref = torch.einsum("bij,bjc->bic", w, v)
+    out = torch.empty(B, N, C, device=DEV, dtype=dtype)
+    hip.call("fdbm_attention", hip.ptr(out), hip.ptr(qkv.to(DEV)), B, N, C, hip.dt_code(dtype))
+    assert (out.float().cpu() - ref).abs().max() < tol
+
+
+def test_temb_and_dense():
+    nf, B = 64, 3
+    fw = rnd(nf, seed=90) * 16
+    w1, b1 = rnd(4 * nf, 2 * nf, seed=91) / math.sqrt(2 * nf), rnd(4 * nf, seed=92) * 0.05
+    w2, b2 = rnd(4 * nf, 4 * nf, seed=93) / math.sqrt(4 * nf), rnd(4 * nf, seed=94) * 0.05
+    t = torch.tensor([1.0, 0.5, 1e-4])
+    sd = {"all_modules.0.W": fw, "all_modules.1.weight": w1, "all_modules.1.bias": b1,
+          "all_modules.2.weight": w2, "all_modules.2.bias": b2}
+    ref = F.silu(onet.time_embedding(sd, t))
+    out = torch.empty(B, 4 * nf, device=DEV)
+    scratch = torch.empty(B, 4 * nf, device=DEV)
+    d = lambda x: x.to(DEV).contiguous()
+    keep = [d(x) for x in (t, fw, w1, b1, w2, b2)]
+    hip.call("fdbm_temb", hip.ptr(out), *[hip.ptr(x) for x in keep], hip.ptr(scratch), B, nf)
+    assert (out.cpu() - ref).abs().max() < 2e-4       # arguments up to ~2000 rad at t = 1e-4
+    assert (out.cpu()[:2] - ref[:2]).abs().max() < 2e-5
+    R = 200
+    wd, bd = rnd(R, 4 * nf, seed=95) / math.sqrt(4 * nf), rnd(R, seed=96)
+    o2 = torch.empty(B, R, device=DEV)
+    keep2 = [d(wd), d(bd)]
+    hip.call("fdbm_dense_rows", hip.ptr(o2), hip.ptr(out), hip.ptr(keep2[0]), hip.ptr(keep2[1]), B, R, 4 * nf)
+    assert (o2.cpu() - F.linear(out.cpu(), wd, bd)).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_stem_pack_unpack_combine(dtype, tol):
+    B, Fq, T, nf = 2, 257, 16, 64
+    x, y = crnd(B, 1, Fq, T, seed=1), crnd(B, 1, Fq, T, seed=2)
+    inp = torch.empty(B, 256, T, 4, device=DEV)
+    hip.call("fdbm_pack_input", hip.ptr(inp), hip.ptr(x.to(DEV)), hip.ptr(y.to(DEV)), B, Fq, 256, T)
+    ref_in = torch.cat((x.real, x.imag, y.real, y.imag), 1)[:, :, :256]
+    assert torch.equal(nchw(inp), ref_in)
+    w, b = rnd(nf, 4, 3, 3, seed=3) / 6, rnd(nf, seed=4) * 0.1
+    out = torch.empty(B, 256, T, nf, device=DEV, dtype=dtype)
+    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    hip.call("fdbm_conv_stem", hip.ptr(out), hip.ptr(inp), hip.ptr(wd), hip.ptr(b.to(DEV)), B, 256, T, nf, hip.dt_code(dtype))
+    assert (nchw(out) - F.conv2d(ref_in, w, b, padding=1)).abs().max() < tol
+    # output layer + Nyquist row
+    pyr = rnd(B, 4, 256, T, seed=5)
+    ow, ob = rnd(2, 4, seed=6), rnd(2, seed=7)
+    s = torch.empty(B, 1, Fq, T, dtype=torch.complex64, device=DEV)
+    hip.call("fdbm_unpack_output", hip.ptr(s), hip.ptr(nhwc(pyr)), hip.ptr(ow.to(DEV)), hip.ptr(ob.to(DEV)), B, Fq, 256, T)
+    r = F.conv2d(pyr, ow[:, :, None, None], ob)
+    ref = torch.cat((torch.complex(r[:, 0], r[:, 1])[:, None], torch.zeros(B, 1, 1, T, dtype=torch.complex64)), 2)
+    assert (s.cpu() - ref).abs().max() < 1e-6
+    # Combine
+    C = 64
+    h, p = rnd(B, C, 8, 8, seed=8), rnd(B, 4, 8, 8, seed=9)
+    cw, cb = rnd(C, 4, seed=10), rnd(C, seed=11)
+    hd = nhwc(h, dtype)
+    hip.call("fdbm_combine", hip.ptr(hd), hip.ptr(hd), hip.ptr(nhwc(p)), hip.ptr(cw.to(DEV)), hip.ptr(cb.to(DEV)), B * 64, C, hip.dt_code(dtype))
+    ref = F.conv2d(p, cw[:, :, None, None], cb) + h.to(dtype).float()
+    assert (nchw(hd) - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("tag,n_fft,hop,window", [("512", 512, 256, "sqrthann"), ("510", 510, 128, "hann")])
+def test_frontend(golden, tag, n_fft, hop, window):
+    from fdbm_amd.frontend import SpecFrontend
+    g = golden("frontend_" + tag)
+    fe = SpecFrontend(n_fft=n_fft, hop_length=hop, window=window, device=DEV)
+    wave = torch.from_numpy(g["wave"]).to(DEV)
+    S = fe.stft(wave)
+    assert S.shape == g["stft"].shape
+    assert (S.cpu() - torch.from_numpy(g["stft"])).abs().max() < 2e-4
+    Y = fe.spec_forward_padded(wave, pad_mode="reflection")
+    assert (Y.cpu() - torch.from_numpy(g["pad_reflect"])).abs().max() < 2e-5
+    Y0 = fe.spec_forward_padded(wave, pad_mode="zero_pad")
+    assert (Y0.cpu() - torch.from_numpy(g["pad_zero"])).abs().max() < 2e-5
+    x = fe.to_audio(torch.from_numpy(g["spec_fwd"]).to(DEV), wave.shape[-1])
+    assert (x.cpu() - torch.from_numpy(g["istft"])).abs().max() < 5e-6
+    # round trip through the padded spectrogram (what the drivers do)
+    x2 = fe.to_audio(Y[0, 0] if Y.dim() == 4 else Y, wave.shape[-1])
+    assert (x2.cpu() - wave.cpu()).abs().max() < 1e-5

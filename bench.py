@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Benchmark of the reverse-sampling hot path (BASELINE.json metric: real-time factor at
+N=30 steps on 16 kHz / 4 s clips).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+
+A "step" is one pass of the hot path over one batch of synthetic clips already resident
+in HBM:  normalise -> STFT + compression + time padding -> N=30 ODE-EI sampler (30 NCSN++
+evaluations + 30 fused state updates, one HIP graph) -> inverse compression + iSTFT ->
+renormalise [-> RCCL all-gather of the enhanced spectrograms when N > 1].
+Workload at every N (weak scaling): BASELINE.json configs[1] per rank - one synthetic
+4 s clip, ncsnpp_v2 (65.6 M parameters, deterministic synthetic weights), bridge sb/bb,
+bf16 storage + fp32 accumulate.  --batch 64 gives configs[2].
+
+Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (conv_igemm_kernel,
+MFMA-bound) from HIP-event timings of every conv launch of one forward; `cpu_baseline`
+times the CPU oracle (a port, oracle/) on a bounded sample on the host cores.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR = 16000
+CLIP_SECONDS = 4.0
+BF16_DENSE_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+F32_MFMA_PEAK_TFLOPS = 157.3
+
+
+def synth_clips(B, seed, device):
+    """Speech-like band-limited harmonic signal + white noise at 0..10 dB SNR, peak-normalised."""
+    n = int(SR * CLIP_SECONDS)
+    out = np.empty((B, n), np.float32)
+    for b in range(B):
+        g = np.random.Generator(np.random.Philox(seed * 100003 + b))
+        t = np.arange(n) / SR
+        f0 = g.uniform(90, 250)
+        sig = sum(np.sin(2 * np.pi * f0 * (k + 1) * t + g.uniform(0, 6.28)) / (k + 1) for k in range(12))
+        env = 0.5 + 0.5 * np.sin(2 * np.pi * g.uniform(1.5, 4.0) * t) ** 2
+        sig = sig * env
+        snr_db = g.uniform(0, 10)
+        noise = g.standard_normal(n)
+        noise *= np.sqrt(np.mean(sig ** 2) / (np.mean(noise ** 2) * 10 ** (snr_db / 10)))
+        x = sig + noise
+        out[b] = (x / np.max(np.abs(x))).astype(np.float32)
+    return torch.from_numpy(out).to(device)
+
+
+class HotPath:
+    """waveforms in HBM -> enhanced waveforms in HBM, everything through libfdbm_hip.so."""
+
+    def __init__(self, device, dtype, n_steps, batch, backbone="ncsnpp_v2", bridge="sb", schedule="bb"):
+        import fdbm_amd
+        from fdbm_amd.frontend import SpecFrontend, pad_mode_for
+        self.dev = device
+        self.B = batch
+        self.net = fdbm_amd.BackboneRegistry.get_by_name(backbone)(dtype=dtype, device=device)
+        self.fe = SpecFrontend(n_fft=512, hop_length=256, window="sqrthann", device=device)   # config.yaml:35-38
+        self.bridge = fdbm_amd.Bridge(bridge, N=n_steps, sampler_type="ode_ei", noise_schedule=schedule)
+        self.pad_mode = pad_mode_for(backbone)
+        self.gen = torch.Generator().manual_seed(0)
+
+    def enhance(self, wave):
+        """infer_folder.py:102-121 per batch.  Returns (enhanced waveform, enhanced spectrogram)."""
+        nf = wave.abs().amax(dim=1, keepdim=True)
+        Y = self.fe.spec_forward_padded(wave / nf, self.pad_mode)
+        X = self.bridge.sampler(self.net, Y, generator=self.gen)
+        x_hat = self.fe.to_audio(X[:, 0], wave.shape[-1]) * nf
+        peak = x_hat.abs().amax(dim=1, keepdim=True)
+        x_hat = torch.where(peak > 1.0, x_hat / peak * 0.95, x_hat)
+        return x_hat, X
+
+
+def time_conv_launches(net, B, F, T, reps=3):
+    """HIP-event time of every conv_igemm launch of one forward (eager, same stream)."""
+    from fdbm_amd import hip
+    prog = net.program(B, F, T)
+    prog.run()
+    torch.cuda.synchronize()
+    conv_ids = [i for i, (opc, _, _) in enumerate(prog.ops) if opc == hip.OP_CONV]
+    best = [float("inf")] * len(conv_ids)
+    fwd_ms = float("inf")
+    for _ in range(reps):
+        evs = []
+        e0 = torch.cuda.Event(enable_timing=True); e0.record()
+        lo = 0
+        for i in conv_ids:
+            if i > lo:
+                prog.run_range(lo, i)
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); prog.run_range(i, i + 1); b.record()
+            evs.append((a, b))
+            lo = i + 1
+        prog.run_range(lo, prog.n_ops)
+        e1 = torch.cuda.Event(enable_timing=True); e1.record()
+        torch.cuda.synchronize()
+        for k, (a, b) in enumerate(evs):
+            best[k] = min(best[k], a.elapsed_time(b))
+        fwd_ms = min(fwd_ms, e0.elapsed_time(e1))
+    # algorithmic flops of each conv launch (all segments), whole batch
+    flops = []
+    for ca in prog.keep_conv:
+        k = sum(ca.seg[s].cin * ca.seg[s].taps for s in range(ca.nseg))
+        flops.append(2.0 * ca.B * ca.H * ca.W * ca.Cout * k)
+    return best, flops, fwd_ms, prog
+
+
+def cpu_baseline(n_forwards, n_steps):
+    """Times the CPU oracle (oracle/, a port of the reference path) on the host cores."""
+    from fdbm_amd.arch import Spec, VARIANTS
+    from fdbm_amd.weights import fill_state_dict
+    from oracle import ncsnpp as onet, frontend as ofe
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))          # the GPU box's CPU share for one GPU is 16 cores
+    torch.set_num_threads(cores)
+    hp = VARIANTS["ncsnpp_v2"]
+    model = onet.Model(fill_state_dict(Spec(**hp).param_shapes(), seed=0), hp)
+    wave = synth_clips(1, 0, "cpu")
+    t0 = time.time()
+    Y = ofe.pad_spec(ofe.spec_fwd(ofe.stft(wave / wave.abs().max()))[:, None], "reflection")
+    t_front = time.time() - t0
+    xt = Y.clone()
+    t0 = time.time()
+    for i in range(n_forwards):
+        s = model(xt, Y, torch.tensor([1.0 - 0.03 * i]))
+        xt = 0.9 * xt + 0.1 * s
+    t_fwd = (time.time() - t0) / n_forwards
+    t0 = time.time()
+    ofe.istft(ofe.spec_back(xt[:, 0]), wave.shape[-1])
+    t_back = time.time() - t0
+    total = t_front + n_steps * t_fwd + t_back
+    return dict(value=CLIP_SECONDS / total, unit="x real-time (audio-s/wall-s)", cores=cores, kind="port",
+                sample=f"{n_forwards} of the {n_steps} backbone evaluations of one 4 s clip (fp32 torch CPU ops, "
+                       f"{cores} threads, {t_fwd:.2f} s each) + full front-end/back-end; sampler extrapolated x{n_steps}/{n_forwards}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="clips per rank per step (1 = configs[1], 64 = configs[2])")
+    ap.add_argument("--N", type=int, default=30, help="sampler steps")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--backbone", default="ncsnpp_v2")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-forwards", type=int, default=2)
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32-parity-mode and batch-64 side measurements")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+
+    hp = HotPath(dev, dtype, args.N, args.batch, backbone=args.backbone)
+    wave = synth_clips(args.batch, 1000 + rank, dev)            # resident in HBM before timing
+
+    def step():
+        x_hat, X = hp.enhance(wave)
+        if world > 1:
+            import torch.distributed as dist
+            xr = torch.view_as_real(X.contiguous())
+            gathered = [torch.empty_like(xr) for _ in range(world)] if rank == 0 else None
+            dist.gather(xr, gathered, dst=0)                     # enhanced spectrograms only, over RCCL/xGMI
+        return x_hat
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    assert torch.isfinite(out).all()
+
+    audio_s = world * args.steps * args.batch * CLIP_SECONDS
+    rtf = audio_s / elapsed
+    if rank != 0:
+        if world > 1:
+            import torch.distributed as dist
+            dist.destroy_process_group()
+        return
+
+    F, T = 257, 256
+    flops_fwd = hp.net.flops_per_forward(256, T)
+    result = {
+        "metric": "real-time factor (audio-sec/wall-sec) @ N=30 steps, 16 kHz 4 s clips",
+        "value": rtf, "unit": "x real-time (audio-s / wall-s)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[{1 if args.batch == 1 else 2}]: {args.batch} synthetic 4 s 16 kHz clip(s) per rank per step, "
+                               f"{args.backbone} (deterministic synthetic weights), bridge sb/bb, ode_ei N={args.N}, "
+                               "STFT 512/256 sqrt-Hann -> [257 x 256] complex spectrogram",
+                   "batch_per_rank": args.batch, "sampler_steps": args.N, "parallelism": f"dp{world} (utterance sharding, gather of spectrograms)"},
+        "whole_step_tflops": world * args.batch * args.N * flops_fwd / (elapsed / args.steps) / 1e12,
+    }
+
+    # ---- roofline of the dominant kernel (conv_igemm_kernel) ---------------------------
+    times, flops, fwd_ms, prog = time_conv_launches(hp.net, args.batch, F, T)
+    t_conv = sum(times) * 1e-3
+    achieved = sum(flops) / t_conv / 1e12
+    peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+    result["roofline"] = {
+        "bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+        "frac": achieved / peak, "traffic": None,
+        "launches_per_forward": len(times), "avg_launch_us": 1e3 * sum(times) / len(times),
+        "algorithmic_gflop_per_launch_avg": sum(flops) / len(times) / 1e9,
+        "conv_ms_per_forward": 1e3 * t_conv, "forward_ms_eager": fwd_ms,
+        "forward_ms_in_graph": 1e3 * elapsed / args.steps / args.N,
+    }
+
+    if not args.no_extras:
+        extras = {}
+        try:
+            hp32 = HotPath(dev, torch.float32, args.N, 1, backbone=args.backbone)
+            w1 = wave[:1]
+            hp32.enhance(w1); torch.cuda.synchronize()
+            t1 = time.perf_counter(); hp32.enhance(w1); hp32.enhance(w1); torch.cuda.synchronize()
+            extras["fp32_parity_mode_rtf_b1"] = 2 * CLIP_SECONDS / (time.perf_counter() - t1)
+            del hp32
+            if args.batch == 1:
+                hp64 = HotPath(dev, dtype, args.N, 64, backbone=args.backbone)
+                w64 = synth_clips(64, 77, dev)
+                hp64.enhance(w64); torch.cuda.synchronize()
+                t1 = time.perf_counter(); hp64.enhance(w64); torch.cuda.synchronize()
+                dt = time.perf_counter() - t1
+                extras["batch64_rtf"] = 64 * CLIP_SECONDS / dt
+                extras["batch64_whole_step_tflops"] = 64 * args.N * flops_fwd / dt / 1e12
+                del hp64
+        except Exception as e:       # side measurements must never kill the headline line
+            extras["error"] = repr(e)
+        result["extras"] = extras
+
+    if not args.no_cpu_baseline and world == 1:
+        result["cpu_baseline"] = cpu_baseline(args.cpu_forwards, args.N)
+    print(json.dumps(result))
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

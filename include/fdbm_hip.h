@@ -70,8 +70,11 @@ int fdbm_unpack_output(void* out, const float* pyr, const float* w, const float*
 /* ------------------------------------------------------------------ time embedding
  * GaussianFourierProjection(log t) -> Linear -> SiLU -> Linear, then SiLU again (every
  * consumer applies act(temb) first): out f32 [B][4nf] = silu(temb).  The Fourier argument
- * is formed as ((log t * W) * 2) * pi in fp32 (layerspp.py:40; ncsnpp_v2.py:252-270). */
-int fdbm_temb(float* out_act, const float* t, const float* fourier_w, const float* w1,
+ * is formed as ((log t * W) * 2) * pi in fp32 (layerspp.py:40; ncsnpp_v2.py:252-270).
+ * log_t is log(t) evaluated by the HOST (fp32): arguments reach thousands of radians, so a
+ * 1-ulp difference between two libms' logf moves sin/cos by up to 1e-4 (hard
+ * part 7); with the host's log the argument is bit-identical to the reference's. */
+int fdbm_temb(float* out_act, const float* log_t, const float* fourier_w, const float* w1,
               const float* b1, const float* w2, const float* b2, float* scratch, int B, int nf,
               void* stream);
 
@@ -95,10 +98,13 @@ int fdbm_gn_stats(float* partial /*[B][nsplit][G][2]*/, const void* src0, int C0
                   void* stream);
 int fdbm_gn_finalize(float* mean_rstd /*[B][G][2]*/, const float* partial, int B, int nsplit,
                      int G, int64_t count, float eps, void* stream);
-/* out = act(gn(cat(src0, src1))) written as one NHWC tensor of C0+C1 channels. */
+/* out = act(gn(cat(src0, src1))) written as one NHWC tensor of C0+C1 channels.
+ * stats: nsplit == 0 -> final mean_rstd [B][G][2]; nsplit > 0 -> the PARTIAL sums of
+ * fdbm_gn_stats, reduced in-kernel (fp64, fixed order) with `count` elements per group, which
+ * saves the finalize launch. */
 int fdbm_gn_apply(void* out, const void* src0, int C0, const void* src1, int C1,
-                  const float* mean_rstd, const float* gamma, const float* beta, int B, int HW,
-                  int G, int silu, int dtype, void* stream);
+                  const float* stats, int nsplit, int64_t count, float eps, const float* gamma,
+                  const float* beta, int B, int HW, int G, int silu, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ FIR resampling
  * Generic upfirdn2d, the reference's own native-op boundary
@@ -111,12 +117,12 @@ int fdbm_upfirdn2d(float* out, const float* in, const float* kernel, int major, 
 
 /* Fast path for the only configuration the network uses: FIR [1,3,3,1], factor 2
  * (upsample_2d / downsample_2d, up_or_down_sampling.py:195-257), NHWC, dtype in {f32,bf16}.
- * One read of x produces up to two outputs: out_plain = resample(x) and, when mean_rstd is
- * non-NULL, out_act = resample(silu(gn(x))) (ResnetBlockBigGANpp.forward,
+ * One read of x produces up to two outputs: out_plain = resample(x) and, when stats is
+ * non-NULL (same convention as fdbm_gn_apply), out_act = resample(silu(gn(x))) (ResnetBlockBigGANpp.forward,
  * layerspp.py:243-258).  Either output pointer may be NULL.  up != 0: upsample. */
-int fdbm_resample2x(void* out_plain, void* out_act, const void* in, const float* mean_rstd,
-                    const float* gamma, const float* beta, int B, int H, int W, int C, int G,
-                    int up, int dtype, void* stream);
+int fdbm_resample2x(void* out_plain, void* out_act, const void* in, const float* stats, int nsplit,
+                    int64_t count, float eps, const float* gamma, const float* beta, int B, int H,
+                    int W, int C, int G, int up, int dtype, void* stream);
 
 /* ------------------------------------------------------------------ convolution (implicit GEMM on MFMA)
  * nn.Conv2d 3x3 pad 1 / 1x1 (layers.py:100-105,118-124) and NIN (layers.py:546-555) as one
@@ -147,11 +153,16 @@ typedef struct {
   int32_t B, H, W, Cout, CoutPad;
   int32_t dt_in;        /* FDBM_F32 | FDBM_BF16 : sources and packed weights        */
   int32_t dt_out;       /* FDBM_F32 | FDBM_BF16 (f32 out with bf16 in is allowed)   */
+  void* workspace;      /* optional split-K scratch (fp32 slabs) or NULL            */
+  int64_t workspace_bytes;
 } fdbm_conv_args;
 
 int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream);
 /* elements per k-step for a dtype (64 for bf16, 32 for f32) */
 int fdbm_conv_kc(int dtype);
+/* tile / split-K plan the launcher will use for M pixels, Cout channels, nk k-steps
+ * (the caller sizes `workspace` as ksplit * M * Cout * 4 bytes when ksplit > 1) */
+int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int* ksplit);
 
 /* Combine('sum'): out = conv1x1(4->C)(pyr) + h (layerspp.py:52-57; ncsnpp_v2.py:302-305).
  * pyr f32 [M][4], w f32 [C][4], bias f32 [C], h/out dtype [M][C]; out may alias h. */

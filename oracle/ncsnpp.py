@@ -112,8 +112,12 @@ def attnblock(sd, p, x):
 def time_embedding(sd, t):
     """Fourier features of log t -> Linear -> SiLU -> Linear (ncsnpp_v2.py:252-270).
     The argument is formed left to right: ((log t * W) * 2) * pi  (layerspp.py:40)."""
-    x = torch.log(t)
-    proj = x[:, None] * sd["all_modules.0.W"][None, :] * 2 * np.pi
+    # The argument is DEFINED in fp32 (fp32 log, fp32 products): at t = 1e-4 it reaches
+    # thousands of radians, so evaluating it in another precision is a different function.
+    # Only sin/cos and everything after run in the oracle's working precision (fp32 or fp64).
+    W = sd["all_modules.0.W"]
+    x = torch.log(t.to(torch.float32))
+    proj = (x[:, None] * W.to(torch.float32)[None, :] * 2 * np.pi).to(W.dtype)
     temb = torch.cat([torch.sin(proj), torch.cos(proj)], dim=-1)
     temb = F.linear(temb, sd["all_modules.1.weight"], sd["all_modules.1.bias"])
     return F.linear(F.silu(temb), sd["all_modules.2.weight"], sd["all_modules.2.bias"])

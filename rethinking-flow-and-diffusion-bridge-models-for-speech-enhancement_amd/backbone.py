@@ -173,7 +173,8 @@ class HipNCSNpp:
         prog = self.program(B, F, T)
         prog.x_in.copy_(x)
         prog.y_in.copy_(y)
-        prog.t_in.copy_(t.to(device=self.device, dtype=torch.float32).reshape(B))
+        # log t on the host: see fdbm_temb in include/fdbm_hip.h
+        prog.t_in.copy_(torch.log(t.detach().to(device="cpu", dtype=torch.float32).reshape(B)))
         prog.run()
         return prog.s_out.clone()
 

@@ -46,6 +46,56 @@ template <> struct DT<bf16_t> {
 };
 
 __device__ __forceinline__ float silu_f(float x) { return x * __frcp_rn(1.0f + __expf(-x)); }
+// parity mode (f32 storage): correctly rounded-ish exp and a true division, like the host libm
+__device__ __forceinline__ float silu_precise(float x) { return x / (1.0f + expf(-x)); }
+template <typename T> __device__ __forceinline__ float silu_t(float x) {
+  if constexpr (sizeof(T) == 4) return silu_precise(x); else return silu_f(x);
+}
+
+// GroupNorm statistics -> per-channel scale/shift in LDS (s_ss[0..C) scale, s_ss[C..2C) shift).
+// stats: nsplit == 0: final [B][G][2] (mean, rstd);  nsplit > 0: partial (sum, sumsq)
+// [B][nsplit][G][2] reduced here in fp64 in a fixed order.  G <= 32, blockDim.x == 256.
+__device__ __forceinline__ void gn_scale_shift(float* s_ss, double* s_red /*[8][32][2]*/,
+                                               const float* __restrict__ stats, int nsplit,
+                                               double inv_count, float eps, int b, int C, int G,
+                                               const float* __restrict__ gamma,
+                                               const float* __restrict__ beta) {
+  __shared__ float s_mr[64];
+  const int tid = threadIdx.x;
+  if (nsplit == 0) {
+    if (tid < 2 * G) s_mr[tid] = stats[(int64_t)b * G * 2 + tid];
+  } else {
+    const int g = tid & 31, part = tid >> 5;
+    double a0 = 0.0, a1 = 0.0;
+    if (g < G)
+      for (int sp = part; sp < nsplit; sp += 8) {
+        const float* q = stats + (((int64_t)b * nsplit + sp) * G + g) * 2;
+        a0 += (double)q[0];
+        a1 += (double)q[1];
+      }
+    s_red[(part * 32 + g) * 2] = a0;
+    s_red[(part * 32 + g) * 2 + 1] = a1;
+    __syncthreads();
+    if (tid < G) {
+      double t0 = 0.0, t1 = 0.0;
+      for (int q = 0; q < 8; ++q) { t0 += s_red[(q * 32 + tid) * 2]; t1 += s_red[(q * 32 + tid) * 2 + 1]; }
+      const double mean = t0 * inv_count;
+      double var = t1 * inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mr[2 * tid] = (float)mean;
+      s_mr[2 * tid + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int c = tid; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float sc = s_mr[2 * g + 1] * gamma[c];
+    s_ss[c] = sc;
+    s_ss[C + c] = beta[c] - s_mr[2 * g] * sc;
+  }
+  __syncthreads();
+}
 
 // 16-byte vector <-> float[vecw]
 template <typename T> struct Vec16;

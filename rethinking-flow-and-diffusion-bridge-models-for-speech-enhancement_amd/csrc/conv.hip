@@ -15,8 +15,10 @@
 // (row>>1)&7 so the 16 lanes of every ds_read_b128 group hit 16 distinct bank slots.
 // f32 path: v_mfma_f32_16x16x4_f32 consumes the 4 floats of the same b128 read as four
 // successive k-groups {j, 4+j, 8+j, 12+j} (identical permutation on both operands).
-// Pipeline: global loads of k-step t+1 are issued into registers before the MFMAs of
-// step t and written to the other LDS buffer after them; one barrier per k-step.
+// Pipeline: global loads run two k-steps ahead of the MFMAs (two register sets), are written
+// to the other LDS buffer after the MFMAs of the step before them; one barrier per k-step.
+// Small-M layers (the 4x4 ... 32x32 levels at batch 1) split the k-steps over grid.z and a
+// second kernel sums the fp32 slabs and applies the epilogue (weights are streamed once).
 #include "common.h"
 
 struct ConvParams {
@@ -31,6 +33,8 @@ struct ConvParams {
   void* out;
   int B, H, W, Cout, CoutPad;
   int nk;
+  int ksplit;       // grid.z: k-steps are split over this many workgroups
+  float* partial;   // fp32 slabs [ksplit][M][Cout] when ksplit > 1
 };
 
 template <typename T> struct Mfma;
@@ -63,16 +67,15 @@ template <> struct OutVec<bf16_t> {
   }
 };
 
-template <typename T, typename TO, int BN>
+template <typename T, typename TO, int BM, int BN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
-  constexpr int BM = 128;
   constexpr int KC = 128 / (int)sizeof(T);   // elements per k-step row
   constexpr int VW = 16 / (int)sizeof(T);    // elements per 16-byte chunk
-  constexpr int WTN = BN / 2;
-  constexpr int NT = WTN / 16;
-  constexpr int MT = 4;
-  constexpr int WROWS = BN / 32;
+  constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile (4 waves as 2 x 2)
+  constexpr int MT = WTM / 16, NT = WTN / 16;
+  constexpr int AROWS = BM / 32, WROWS = BN / 32;   // 16-byte loads per thread per k-step
   constexpr int BUF = (BM + BN) * 128;
+  constexpr bool F32 = sizeof(T) == 4;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -86,14 +89,20 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
 
+  // ---- split-K: this block owns k-steps [kbeg, kend) ------------------------------------
+  const int kper = (p.nk + p.ksplit - 1) / p.ksplit;
+  const int kbeg = blockIdx.z * kper;
+  const int kend = min(p.nk, kbeg + kper);
+  const int nloc = kend - kbeg;
+
   // ---- loader mapping: thread -> (16-byte chunk, rows lrow + 32 i) ------------------
   const int lchunk = tid & 7;
   const int lrow = tid >> 3;
-  int py[4], px[4];
-  int64_t pbase[4];
-  bool pval[4];
+  int py[AROWS], px[AROWS];
+  int64_t pbase[AROWS];
+  bool pval[AROWS];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < AROWS; ++i) {
     const int64_t m = m0 + lrow + 32 * i;
     pval[i] = m < M;
     const int64_t mm = pval[i] ? m : 0;
@@ -104,28 +113,38 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     pbase[i] = b * HW;
   }
 
-  uint4 areg[4], wreg[WROWS];
+  uint4 areg[2][AROWS], wreg[2][WROWS];
   int ks = 0, ktap = 0, kc = 0;     // segment / tap / chunk of the NEXT k-step to load
+  for (int i = 0; i < kbeg; ++i) {  // advance the cursor to this block's first k-step
+    const fdbm_conv_seg& sg = p.seg[ks];
+    const int nchunks = (sg.cin + KC - 1) / KC;
+    if (++kc == nchunks) {
+      kc = 0;
+      if (++ktap == sg.taps) { ktap = 0; ++ks; }
+    }
+  }
 
-  auto load_regs = [&](int kidx) {
+  // Loads are unconditional (clamped address, then a select): a branch around each load makes
+  // hipcc wait for every load separately - one L2 round trip per row instead of one per k-step.
+  auto load_regs = [&](uint4* ar, uint4* wr, int kidx) {
     const fdbm_conv_seg& sg = p.seg[ks];
     const int dy = sg.taps == 9 ? ktap / 3 - 1 : 0;
     const int dx = sg.taps == 9 ? ktap % 3 - 1 : 0;
     const int cvalid = min(KC, sg.cin - kc * KC);
     const bool cok = lchunk * VW < cvalid;
-    const T* src = reinterpret_cast<const T*>(sg.src) + sg.coff + kc * KC + lchunk * VW;
+    const T* src = reinterpret_cast<const T*>(sg.src) + sg.coff + (cok ? kc * KC + lchunk * VW : 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AROWS; ++i) {
       const int iy = py[i] + dy, ix = px[i] + dx;
       const bool ok = cok && pval[i] && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      uint4 v = {0u, 0u, 0u, 0u};
-      if (ok) v = *reinterpret_cast<const uint4*>(src + (pbase[i] + (int64_t)iy * W + ix) * sg.C);
-      areg[i] = v;
+      const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+      uint4 v = *reinterpret_cast<const uint4*>(src + (pbase[i] + (int64_t)iyc * W + ixc) * sg.C);
+      if (!ok) v = uint4{0u, 0u, 0u, 0u};
+      ar[i] = v;
     }
     const T* wp = reinterpret_cast<const T*>(p.w) + ((int64_t)kidx * p.CoutPad + n0 + lrow) * KC + lchunk * VW;
 #pragma unroll
-    for (int i = 0; i < WROWS; ++i) wreg[i] = *reinterpret_cast<const uint4*>(wp + (int64_t)32 * i * KC);
-    // advance the k-step cursor
+    for (int i = 0; i < WROWS; ++i) wr[i] = *reinterpret_cast<const uint4*>(wp + (int64_t)32 * i * KC);
     const int nchunks = (sg.cin + KC - 1) / KC;
     if (++kc == nchunks) {
       kc = 0;
@@ -133,18 +152,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
   };
 
-  auto write_lds = [&](int buf) {
+  auto write_lds = [&](int buf, const uint4* ar, const uint4* wr) {
     unsigned char* A = smem + buf * BUF;
     unsigned char* Wt = A + BM * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < AROWS; ++i) {
       const int row = lrow + 32 * i;
-      *reinterpret_cast<uint4*>(A + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = areg[i];
+      *reinterpret_cast<uint4*>(A + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = ar[i];
     }
 #pragma unroll
     for (int i = 0; i < WROWS; ++i) {
       const int row = lrow + 32 * i;
-      *reinterpret_cast<uint4*>(Wt + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = wreg[i];
+      *reinterpret_cast<uint4*>(Wt + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = wr[i];
     }
   };
 
@@ -160,26 +179,50 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   auto compute = [&](int buf) {
     const unsigned char* A = smem + buf * BUF;
     const unsigned char* Wt = A + BM * 128;
+    if constexpr (!F32) {
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const int cidx = kk * 4 + fk;
-      uint4 wf[NT], af[MT];
+      for (int kk = 0; kk < 2; ++kk) {
+        const int cidx = kk * 4 + fk;
+        uint4 wf[NT], af[MT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * WTN + j * 16 + frow;
-        wf[j] = *reinterpret_cast<const uint4*>(Wt + row * 128 + ((cidx ^ ((row >> 1) & 7)) << 4));
-      }
+        for (int j = 0; j < NT; ++j) {
+          const int row = wn * WTN + j * 16 + frow;
+          wf[j] = *reinterpret_cast<const uint4*>(Wt + row * 128 + ((cidx ^ ((row >> 1) & 7)) << 4));
+        }
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = wm * 64 + i * 16 + frow;
-        af[i] = *reinterpret_cast<const uint4*>(A + row * 128 + ((cidx ^ ((row >> 1) & 7)) << 4));
-      }
-      if constexpr (sizeof(T) == 2) {
+        for (int i = 0; i < MT; ++i) {
+          const int row = wm * WTM + i * 16 + frow;
+          af[i] = *reinterpret_cast<const uint4*>(A + row * 128 + ((cidx ^ ((row >> 1) & 7)) << 4));
+        }
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int i = 0; i < MT; ++i) Mfma<bf16_t>::run(wf[j], af[i], acc[j][i]);
-      } else {
+      }
+    } else {
+      // fp32 parity mode: two-level summation.  The 32 channels of this k-step are summed in a
+      // fresh accumulator (an exact-fma chain of length 32 inside the MFMAs), which is then
+      // added to the running sum: the rounding error grows like sqrt(32) + sqrt(#k-steps)
+      // instead of sqrt(K) for one chain over K = 1152 ... 4608.
+      f32x4 part[NT][MT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) part[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int cidx = kk * 4 + fk;
+        uint4 wf[NT], af[MT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int row = wn * WTN + j * 16 + frow;
+          wf[j] = *reinterpret_cast<const uint4*>(Wt + row * 128 + ((cidx ^ ((row >> 1) & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const int row = wm * WTM + i * 16 + frow;
+          af[i] = *reinterpret_cast<const uint4*>(A + row * 128 + ((cidx ^ ((row >> 1) & 7)) << 4));
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -188,32 +231,61 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
             for (int i = 0; i < MT; ++i) {
               const float a = reinterpret_cast<const float*>(&wf[j])[q];
               const float b = reinterpret_cast<const float*>(&af[i])[q];
-              acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j][i], 0, 0, 0);
+              part[j][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, part[j][i], 0, 0, 0);
             }
       }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] += part[j][i];
     }
   };
 
-  // ---- main loop -----------------------------------------------------------------------
-  const int nk = p.nk;
-  load_regs(0);
-  write_lds(0);
-  __syncthreads();
-  for (int t = 0; t < nk; ++t) {
-    const int cur = t & 1;
-    if (t + 1 < nk) load_regs(t + 1);
-    compute(cur);
-    if (t + 1 < nk) write_lds(cur ^ 1);
+  // ---- main loop: loads run two k-steps ahead of the MFMAs ------------------------------
+  //   iteration t:  issue loads of step t+2 -> regs[t&1] ; MFMAs on LDS buf[t&1] ;
+  //                 regs[(t+1)&1] (issued one iteration ago) -> LDS buf[(t+1)&1] ; barrier
+  if (nloc > 0) {
+    load_regs(areg[0], wreg[0], kbeg);
+    if (nloc > 1) load_regs(areg[1], wreg[1], kbeg + 1);
+    write_lds(0, areg[0], wreg[0]);
     __syncthreads();
+    int t = 0;
+    for (; t + 1 < nloc; t += 2) {
+      if (t + 2 < nloc) load_regs(areg[0], wreg[0], kbeg + t + 2);
+      compute(0);
+      write_lds(1, areg[1], wreg[1]);
+      __syncthreads();
+      if (t + 3 < nloc) load_regs(areg[1], wreg[1], kbeg + t + 3);
+      compute(1);
+      if (t + 2 < nloc) write_lds(0, areg[0], wreg[0]);
+      __syncthreads();
+    }
+    if (t < nloc) compute(0);
   }
 
   // ---- epilogue --------------------------------------------------------------------------
+  const int Cout = p.Cout;
+  if (p.ksplit > 1) {
+    // raw fp32 partial sums -> slab [z][M][Cout]; fdbm's reduce kernel applies the epilogue
+    float* slab = p.partial + (int64_t)blockIdx.z * M * Cout;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int64_t m = m0 + wm * WTM + i * 16 + frow;
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WTN + j * 16 + fk * 4;
+        if (n >= Cout) continue;
+        *reinterpret_cast<f32x4*>(slab + m * Cout + n) = acc[j][i];
+      }
+    }
+    return;
+  }
   TO* out = reinterpret_cast<TO*>(p.out);
   const TO* res = reinterpret_cast<const TO*>(p.res);
-  const int Cout = p.Cout;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int64_t m = m0 + wm * 64 + i * 16 + frow;
+    const int64_t m = m0 + wm * WTM + i * 16 + frow;
     if (m >= M) continue;
     const int64_t b = m / HW;
 #pragma unroll
@@ -240,12 +312,47 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   }
 }
 
-template <typename T, typename TO, int BN>
+// split-K reduction + epilogue: out = (sum_z slab[z] + bias + tbias + res) * scale
+template <typename TO>
+__global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParams p) {
+  const int Cout = p.Cout;
+  const int HW = p.H * p.W;
+  const int64_t M = (int64_t)p.B * HW;
+  const int nv = Cout / 4;
+  const int64_t total = M * nv;
+  TO* out = reinterpret_cast<TO*>(p.out);
+  const TO* res = reinterpret_cast<const TO*>(p.res);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % nv) * 4;
+    const int64_t m = i / nv;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < p.ksplit; ++z) a += *reinterpret_cast<const f32x4*>(p.partial + ((int64_t)z * M + m) * Cout + n);
+    float v[4] = {a[0], a[1], a[2], a[3]};
+    if (p.bias) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+      v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+    }
+    if (p.tbias) {
+      const f32x4 tv = *reinterpret_cast<const f32x4*>(p.tbias + (m / HW) * p.tbias_stride + n);
+      v[0] += tv[0]; v[1] += tv[1]; v[2] += tv[2]; v[3] += tv[3];
+    }
+    if (res) {
+      float r[4];
+      OutVec<TO>::load(res + m * Cout + n, r);
+      v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+    }
+    v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale;
+    OutVec<TO>::store(out + m * Cout + n, v);
+  }
+}
+
+template <typename T, typename TO, int BM, int BN>
 static int launch_conv(const ConvParams& p, hipStream_t st) {
-  constexpr int SMEM = 2 * (128 + BN) * 128;
+  constexpr int SMEM = 2 * (BM + BN) * 128;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, TO, BN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, TO, BM, BN>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) {
       fdbm_set_error("fdbm_conv_igemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -254,13 +361,50 @@ static int launch_conv(const ConvParams& p, hipStream_t st) {
     attr_set = true;
   }
   const int64_t M = (int64_t)p.B * p.H * p.W;
-  dim3 grid((unsigned)((M + 127) / 128), (unsigned)((p.Cout + BN - 1) / BN));
-  conv_igemm_kernel<T, TO, BN><<<grid, 256, SMEM, st>>>(p);
+  dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((p.Cout + BN - 1) / BN), (unsigned)p.ksplit);
+  conv_igemm_kernel<T, TO, BM, BN><<<grid, 256, SMEM, st>>>(p);
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm");
+  if (p.ksplit > 1) {
+    const int64_t total = M * (p.Cout / 4);
+    int g = (int)((total + 255) / 256);
+    if (g > 2048) g = 2048;
+    conv_splitk_reduce_kernel<TO><<<g, 256, 0, st>>>(p);
+    FDBM_LAUNCH_CHECK("fdbm_conv_igemm/reduce");
+  }
   return 0;
 }
 
+template <typename T, typename TO>
+static int launch_conv_tile(const ConvParams& p, int bm, int bn, hipStream_t st) {
+  if (bm == 128 && bn == 128) return launch_conv<T, TO, 128, 128>(p, st);
+  if (bm == 128 && bn == 64) return launch_conv<T, TO, 128, 64>(p, st);
+  if (bm == 64 && bn == 128) return launch_conv<T, TO, 64, 128>(p, st);
+  return launch_conv<T, TO, 64, 64>(p, st);
+}
+
 extern "C" int fdbm_conv_kc(int dtype) { return dtype == FDBM_BF16 ? 64 : 32; }
+
+// Tile / split-K plan for a conv of M pixels, Cout channels, nk k-steps (host side, also used
+// by the caller to size the split-K workspace): fills bm, bn, ksplit.
+extern "C" int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int* ksplit) {
+  const int target = 512;                         // blocks wanted in flight (2 per CU)
+  int BMs = 128, BNs = Cout <= 64 ? 64 : 128;
+  auto blocks = [&](int a, int b) { return ((M + a - 1) / a) * ((Cout + b - 1) / b); };
+  if (blocks(BMs, BNs) < target && BNs == 128 && Cout > 64) BNs = 64;
+  if (blocks(BMs, BNs) < target) BMs = 64;
+  int ks = 1;
+  const int64_t nb = blocks(BMs, BNs);
+  if (nb < 256 && nk >= 4) {
+    ks = (int)(target / nb);
+    if (ks > nk / 2) ks = nk / 2;
+    // keep the fp32 slabs small: ks * M * Cout * 4 bytes <= 8 MiB
+    const int64_t per = M * Cout * 4;
+    while (ks > 1 && ks * per > (8 << 20)) --ks;
+    if (ks < 1) ks = 1;
+  }
+  *bm = BMs; *bn = BNs; *ksplit = ks;
+  return 0;
+}
 
 extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   FDBM_CHECK(a, "fdbm_conv_igemm: null args");
@@ -292,11 +436,15 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   p.res = a->res; p.scale = a->scale; p.out = a->out;
   p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.CoutPad = a->CoutPad;
   p.nk = nk;
+  int bm, bn, ks;
+  const int64_t M = (int64_t)a->B * a->H * a->W;
+  fdbm_conv_plan(M, a->Cout, nk, &bm, &bn, &ks);
+  if (!a->workspace || a->workspace_bytes <= 0) ks = 1;
+  while (ks > 1 && (int64_t)ks * M * a->Cout * 4 > a->workspace_bytes) --ks;
+  p.ksplit = ks;
+  p.partial = reinterpret_cast<float*>(a->workspace);
   hipStream_t st = (hipStream_t)stream;
-  const bool narrow = a->Cout <= 64;
-  if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_BF16)
-    return narrow ? launch_conv<bf16_t, bf16_t, 64>(p, st) : launch_conv<bf16_t, bf16_t, 128>(p, st);
-  if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_F32)
-    return narrow ? launch_conv<bf16_t, float, 64>(p, st) : launch_conv<bf16_t, float, 128>(p, st);
-  return narrow ? launch_conv<float, float, 64>(p, st) : launch_conv<float, float, 128>(p, st);
+  if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_BF16) return launch_conv_tile<bf16_t, bf16_t>(p, bm, bn, st);
+  if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_F32) return launch_conv_tile<bf16_t, float>(p, bm, bn, st);
+  return launch_conv_tile<float, float>(p, bm, bn, st);
 }

@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256) dense_rows_kernel(float* __restrict__ out
         const int nf = K / 2;
         const int j = k < nf ? k : k - nf;
         // ((log t * W) * 2) * pi, every product rounded to fp32 (layerspp.py:40)
-        const float arg = __fmul_rn(__fmul_rn(__fmul_rn(logf(t[b0 + bb]), fw[j]), 2.0f), 3.14159274101257324f);
+        const float arg = __fmul_rn(__fmul_rn(__fmul_rn(t[b0 + bb], fw[j]), 2.0f), 3.14159274101257324f);
         v = k < nf ? sinf(arg) : cosf(arg);
       } else {
         v = act[(int64_t)(b0 + bb) * K + k];
@@ -332,9 +332,10 @@ extern "C" int fdbm_dense_rows(float* out, const float* act, const float* w, con
   return 0;
 }
 
-extern "C" int fdbm_temb(float* out_act, const float* t, const float* fourier_w, const float* w1,
+extern "C" int fdbm_temb(float* out_act, const float* log_t, const float* fourier_w, const float* w1,
                          const float* b1, const float* w2, const float* b2, float* scratch, int B,
                          int nf, void* stream) {
+  const float* t = log_t;
   FDBM_CHECK(out_act && t && fourier_w && w1 && b1 && w2 && b2 && scratch, "fdbm_temb: null pointer");
   const int E = 2 * nf, D = 4 * nf;
   FDBM_CHECK(D * DENSE_BCHUNK * 4 <= 65536, "fdbm_temb: nf=%d too large", nf);
@@ -360,8 +361,11 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias, int B, int H,
                                                         int W, int nf) {
-  extern __shared__ float s_w[];  // [nf][36] + [nf] bias
-  for (int i = threadIdx.x; i < nf * 36; i += blockDim.x) s_w[i] = w[i];
+  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [36][nf] (k-major) + [nf] bias
+  for (int i = threadIdx.x; i < nf * 36; i += blockDim.x) {
+    const int oc = i / 36, k = i % 36;
+    s_w[k * nf + oc] = w[i];
+  }
   for (int i = threadIdx.x; i < nf; i += blockDim.x) s_w[nf * 36 + i] = bias[i];
   __syncthreads();
   const int ncg = nf / 8;   // 8 output channels per thread
@@ -373,31 +377,33 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
   const int x = (int)(p % W);
   const int y = (int)((p / W) % H);
   const int64_t b = p / ((int64_t)W * H);
-  f32x4 tap[9];
+  float tap[36];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
       const int iy = y + ky - 1, ix = x + kx - 1;
-      f32x4 v = {0, 0, 0, 0};
-      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = in[(b * H + iy) * W + ix];
-      tap[ky * 3 + kx] = v;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
+      f32x4 v = in[(b * H + iyc) * W + ixc];
+      if (!ok) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      const int k = (ky * 3 + kx) * 4;
+      tap[k] = v[0]; tap[k + 1] = v[1]; tap[k + 2] = v[2]; tap[k + 3] = v[3];
     }
   float o[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int oc = cg * 8 + j;
-    const float* wr = s_w + oc * 36;
-    float acc = 0.f;
+  for (int j = 0; j < 8; ++j) o[j] = 0.f;
+  // consecutive threads read consecutive 32-byte groups of a k-row: conflict-free b128 reads
 #pragma unroll
-    for (int k = 0; k < 9; ++k) {
-      acc += wr[k * 4 + 0] * tap[k][0];
-      acc += wr[k * 4 + 1] * tap[k][1];
-      acc += wr[k * 4 + 2] * tap[k][2];
-      acc += wr[k * 4 + 3] * tap[k][3];
-    }
-    o[j] = acc + s_w[nf * 36 + oc];
+  for (int k = 0; k < 36; ++k) {
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(s_w + k * nf + cg * 8);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(s_w + k * nf + cg * 8 + 4);
+    const float t = tap[k];
+    o[0] += w0[0] * t; o[1] += w0[1] * t; o[2] += w0[2] * t; o[3] += w0[3] * t;
+    o[4] += w1[0] * t; o[5] += w1[1] * t; o[6] += w1[2] * t; o[7] += w1[3] * t;
   }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] += s_w[nf * 36 + cg * 8 + j];
   T* dst = out + p * nf + cg * 8;
   if constexpr (sizeof(T) == 2) {
     Vec16<T>::store(dst, o);

@@ -89,7 +89,7 @@ extern "C" int fdbm_gn_stats(float* partial, const void* src0, int C0, const voi
   const int vw = dtype == FDBM_BF16 ? 8 : 4;
   FDBM_CHECK(C0 % vw == 0 && C1 % vw == 0, "fdbm_gn_stats: channels (%d,%d) must be multiples of %d", C0, C1, vw);
   FDBM_CHECK(C0 / vw <= 256 && C1 / vw <= 256 && C0 + C1 <= GN_MAXC, "fdbm_gn_stats: too many channels");
-  FDBM_CHECK(G > 0 && (C0 + C1) % G == 0, "fdbm_gn_stats: C=%d not divisible by G=%d", C0 + C1, G);
+  FDBM_CHECK(G > 0 && G <= 32 && (C0 + C1) % G == 0, "fdbm_gn_stats: C=%d not divisible by G=%d (G <= 32)", C0 + C1, G);
   FDBM_CHECK(nsplit >= 1 && nsplit <= HW, "fdbm_gn_stats: bad nsplit %d (HW=%d)", nsplit, HW);
   dim3 grid(nsplit, B);
   hipStream_t st = (hipStream_t)stream;
@@ -133,23 +133,17 @@ extern "C" int fdbm_gn_finalize(float* mean_rstd, const float* partial, int B, i
 template <typename T, bool SILU>
 __global__ void __launch_bounds__(256) gn_apply_kernel(T* __restrict__ out, const T* __restrict__ src0,
                                                        int C0, const T* __restrict__ src1, int C1,
-                                                       const float* __restrict__ mr,
+                                                       const float* __restrict__ stats, int nsplit,
+                                                       double inv_count, float eps,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int HW, int G,
                                                        int chunks) {
   constexpr int VW = DT<T>::vecw;
-  __shared__ float s_scale[GN_MAXC], s_shift[GN_MAXC];
+  __shared__ float s_ss[2 * GN_MAXC];
+  __shared__ double s_red[8 * 32 * 2];
   const int b = blockIdx.y;
   const int C = C0 + C1;
-  const int cpg = C / G;
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    const int g = c / cpg;
-    const float mean = mr[(b * G + g) * 2], rstd = mr[(b * G + g) * 2 + 1];
-    const float sc = rstd * gamma[c];
-    s_scale[c] = sc;
-    s_shift[c] = beta[c] - mean * sc;
-  }
-  __syncthreads();
+  gn_scale_shift(s_ss, s_red, stats, nsplit, inv_count, eps, b, C, G, gamma, beta);
   const int nvec = C / VW;
   const int64_t total = (int64_t)HW * nvec;
   const int64_t per = (total + chunks - 1) / chunks;
@@ -165,28 +159,32 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(T* __restrict__ out, cons
     Vec16<T>::load(src, x);
 #pragma unroll
     for (int k = 0; k < VW; ++k) {
-      float y = x[k] * s_scale[c + k] + s_shift[c + k];
-      x[k] = SILU ? silu_f(y) : y;
+      float y = x[k] * s_ss[c + k] + s_ss[C + c + k];
+      x[k] = SILU ? silu_t<T>(y) : y;
     }
     Vec16<T>::store(out + ((int64_t)b * HW + p) * C + c, x);
   }
 }
 
 extern "C" int fdbm_gn_apply(void* out, const void* src0, int C0, const void* src1, int C1,
-                             const float* mean_rstd, const float* gamma, const float* beta, int B,
-                             int HW, int G, int silu, int dtype, void* stream) {
-  FDBM_CHECK(out && src0 && mean_rstd && gamma && beta, "fdbm_gn_apply: null pointer");
+                             const float* stats, int nsplit, int64_t count, float eps,
+                             const float* gamma, const float* beta, int B, int HW, int G, int silu,
+                             int dtype, void* stream) {
+  FDBM_CHECK(out && src0 && stats && gamma && beta, "fdbm_gn_apply: null pointer");
   FDBM_CHECK((src1 != nullptr) == (C1 > 0), "fdbm_gn_apply: src1/C1 mismatch");
   const int vw = dtype == FDBM_BF16 ? 8 : 4;
   const int C = C0 + C1;
-  FDBM_CHECK(C0 % vw == 0 && C1 % vw == 0 && C <= GN_MAXC && C % G == 0, "fdbm_gn_apply: bad channels (%d,%d) G=%d", C0, C1, G);
+  FDBM_CHECK(C0 % vw == 0 && C1 % vw == 0 && C <= GN_MAXC && G > 0 && G <= 32 && C % G == 0,
+             "fdbm_gn_apply: bad channels (%d,%d) G=%d", C0, C1, G);
+  FDBM_CHECK(nsplit >= 0 && (nsplit == 0 || count > 0), "fdbm_gn_apply: bad nsplit/count");
   const int64_t total = (int64_t)HW * (C / vw);
   int chunks = (int)((total + 2047) / 2048);
   if (chunks > 1024) chunks = 1024;
   if (chunks < 1) chunks = 1;
   dim3 grid(chunks, B);
   hipStream_t st = (hipStream_t)stream;
-#define GN_APPLY(TT, S) gn_apply_kernel<TT, S><<<grid, 256, 0, st>>>((TT*)out, (const TT*)src0, C0, (const TT*)src1, C1, mean_rstd, gamma, beta, HW, G, chunks)
+  const double inv = nsplit > 0 ? 1.0 / (double)count : 0.0;
+#define GN_APPLY(TT, S) gn_apply_kernel<TT, S><<<grid, 256, 0, st>>>((TT*)out, (const TT*)src0, C0, (const TT*)src1, C1, stats, nsplit, inv, eps, gamma, beta, HW, G, chunks)
   if (dtype == FDBM_BF16) { if (silu) GN_APPLY(bf16_t, true); else GN_APPLY(bf16_t, false); }
   else if (dtype == FDBM_F32) { if (silu) GN_APPLY(float, true); else GN_APPLY(float, false); }
   else FDBM_CHECK(false, "fdbm_gn_apply: bad dtype %d", dtype);

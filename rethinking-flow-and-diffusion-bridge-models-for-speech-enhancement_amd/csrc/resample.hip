@@ -73,22 +73,14 @@ extern "C" int fdbm_upfirdn2d(float* out, const float* in, const float* kernel, 
 template <typename T, bool UP, bool PLAIN, bool ACT>
 __global__ void __launch_bounds__(256) resample2x_kernel(
     T* __restrict__ out_plain, T* __restrict__ out_act, const T* __restrict__ in,
-    const float* __restrict__ mr, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const float* __restrict__ stats, int nsplit, double inv_count, float eps,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
     int H, int W, int C, int G, int chunks) {
   constexpr int VW = DT<T>::vecw;
   extern __shared__ float s_ss[];   // [2][C] scale / shift
+  __shared__ double s_red[ACT ? 8 * 32 * 2 : 1];
   const int b = blockIdx.y;
-  if (ACT) {
-    const int cpg = C / G;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      const int g = c / cpg;
-      const float mean = mr[(b * G + g) * 2], rstd = mr[(b * G + g) * 2 + 1];
-      const float sc = rstd * gamma[c];
-      s_ss[c] = sc;
-      s_ss[C + c] = beta[c] - mean * sc;
-    }
-    __syncthreads();
-  }
+  if (ACT) gn_scale_shift(s_ss, s_red, stats, nsplit, inv_count, eps, b, C, G, gamma, beta);
   const int OH = UP ? 2 * H : H / 2, OW = UP ? 2 * W : W / 2;
   const int nvec = C / VW;
   const int64_t total = (int64_t)OH * OW * nvec;
@@ -132,7 +124,7 @@ __global__ void __launch_bounds__(256) resample2x_kernel(
 #pragma unroll
         for (int k = 0; k < VW; ++k) {
           if (PLAIN) accp[k] += wgt * x[k];
-          if (ACT) acca[k] += wgt * silu_f(x[k] * s_ss[c + k] + s_ss[C + c + k]);
+          if (ACT) acca[k] += wgt * silu_t<T>(x[k] * s_ss[c + k] + s_ss[C + c + k]);
         }
       }
     }
@@ -142,12 +134,15 @@ __global__ void __launch_bounds__(256) resample2x_kernel(
   }
 }
 
-extern "C" int fdbm_resample2x(void* out_plain, void* out_act, const void* in, const float* mean_rstd,
+extern "C" int fdbm_resample2x(void* out_plain, void* out_act, const void* in, const float* stats,
+                               int nsplit, int64_t count, float eps,
                                const float* gamma, const float* beta, int B, int H, int W, int C,
                                int G, int up, int dtype, void* stream) {
   FDBM_CHECK(in && (out_plain || out_act), "fdbm_resample2x: null pointer");
-  FDBM_CHECK((out_act != nullptr) == (mean_rstd != nullptr), "fdbm_resample2x: out_act needs mean_rstd (and vice versa)");
-  FDBM_CHECK(!out_act || (gamma && beta && G > 0 && C % G == 0), "fdbm_resample2x: bad GroupNorm arguments");
+  FDBM_CHECK((out_act != nullptr) == (stats != nullptr), "fdbm_resample2x: out_act needs GroupNorm statistics (and vice versa)");
+  FDBM_CHECK(!out_act || (gamma && beta && G > 0 && G <= 32 && C % G == 0 && C <= 1024), "fdbm_resample2x: bad GroupNorm arguments");
+  FDBM_CHECK(nsplit >= 0 && (nsplit == 0 || count > 0), "fdbm_resample2x: bad nsplit/count");
+  const double inv_count = nsplit > 0 ? 1.0 / (double)count : 0.0;
   const int vw = dtype == FDBM_BF16 ? 8 : 4;
   FDBM_CHECK(C % vw == 0, "fdbm_resample2x: C=%d must be a multiple of %d", C, vw);
   FDBM_CHECK(up || (H % 2 == 0 && W % 2 == 0), "fdbm_resample2x: downsampling needs even H, W (got %d x %d)", H, W);
@@ -159,7 +154,7 @@ extern "C" int fdbm_resample2x(void* out_plain, void* out_act, const void* in, c
   dim3 grid(chunks, B);
   const size_t smem = out_act ? 2 * (size_t)C * sizeof(float) : 0;
   hipStream_t st = (hipStream_t)stream;
-#define RS(TT, U, P, A) resample2x_kernel<TT, U, P, A><<<grid, 256, smem, st>>>((TT*)out_plain, (TT*)out_act, (const TT*)in, mean_rstd, gamma, beta, H, W, C, G, chunks)
+#define RS(TT, U, P, A) resample2x_kernel<TT, U, P, A><<<grid, 256, smem, st>>>((TT*)out_plain, (TT*)out_act, (const TT*)in, stats, nsplit, inv_count, eps, gamma, beta, H, W, C, G, chunks)
 #define RS_DISPATCH(TT)                                                         \
   do {                                                                          \
     const bool P_ = out_plain != nullptr, A_ = out_act != nullptr;              \

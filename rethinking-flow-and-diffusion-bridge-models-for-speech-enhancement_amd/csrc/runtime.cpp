@@ -38,12 +38,12 @@ extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* stream) {
         rc = fdbm_gn_finalize(FP(0), CFP(1), I(2), I(3), I(4), o.iarg[5], o.farg[0], stream);
         break;
       case FDBM_OP_GN_APPLY:
-        rc = fdbm_gn_apply(P(0), CP(1), I(2), CP(3), I(4), CFP(5), CFP(6), CFP(7), I(8), I(9),
-                           I(10), I(11), I(12), stream);
+        rc = fdbm_gn_apply(P(0), CP(1), I(2), CP(3), I(4), CFP(5), I(6), o.iarg[7], o.farg[0], CFP(8),
+                           CFP(9), I(10), I(11), I(12), I(13), I(14), stream);
         break;
       case FDBM_OP_RESAMPLE:
-        rc = fdbm_resample2x(P(0), P(1), CP(2), CFP(3), CFP(4), CFP(5), I(6), I(7), I(8), I(9),
-                             I(10), I(11), I(12), stream);
+        rc = fdbm_resample2x(P(0), P(1), CP(2), CFP(3), I(4), o.iarg[5], o.farg[0], CFP(6), CFP(7),
+                             I(8), I(9), I(10), I(11), I(12), I(13), I(14), stream);
         break;
       case FDBM_OP_COMBINE:
         rc = fdbm_combine(P(0), CP(1), CFP(2), CFP(3), CFP(4), o.iarg[5], I(6), I(7), stream);

@@ -19,7 +19,8 @@ class SamplerGraph:
         dev = net.device
         table, t_model = bridge.ei_weight_table("ode" if kind == "ode" else "sde", B)
         self.table = table.to(dev).contiguous()                       # [N,3,B]
-        self.t_tab = (t_model[:, None] * torch.ones(1, B)).to(dev).contiguous()   # [N,B]
+        # model time of each step as log t, evaluated on the host (see fdbm_temb)
+        self.t_tab = torch.log(t_model[:, None] * torch.ones(1, B)).to(dev).contiguous()   # [N,B]
         self.z = None
         if kind == "sde":
             self.z = torch.zeros(self.N, B, 1, F, T, dtype=torch.complex64, device=dev)

@@ -32,7 +32,8 @@ class ConvArgs(ctypes.Structure):
                 ("out", c_void_p),
                 ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
                 ("Cout", ctypes.c_int32), ("CoutPad", ctypes.c_int32),
-                ("dt_in", ctypes.c_int32), ("dt_out", ctypes.c_int32)]
+                ("dt_in", ctypes.c_int32), ("dt_out", ctypes.c_int32),
+                ("workspace", c_void_p), ("workspace_bytes", c_i64)]
 
 
 class Op(ctypes.Structure):
@@ -55,9 +56,9 @@ _SIGS = {
     "fdbm_conv_stem": [c_void_p] * 4 + [c_int] * 5,
     "fdbm_gn_stats": [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 5,
     "fdbm_gn_finalize": [c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_float],
-    "fdbm_gn_apply": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p] + [c_int] * 5,
+    "fdbm_gn_apply": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_i64, c_float, c_void_p, c_void_p] + [c_int] * 5,
     "fdbm_upfirdn2d": [c_void_p] * 3 + [c_int] * 14,
-    "fdbm_resample2x": [c_void_p] * 6 + [c_int] * 7,
+    "fdbm_resample2x": [c_void_p] * 4 + [c_int, c_i64, c_float, c_void_p, c_void_p] + [c_int] * 7,
     "fdbm_conv_igemm": [ctypes.POINTER(ConvArgs)],
     "fdbm_combine": [c_void_p] * 5 + [c_i64, c_int, c_int],
     "fdbm_attention": [c_void_p, c_void_p] + [c_int] * 4,
@@ -67,7 +68,7 @@ _SIGS = {
     "fdbm_pad_spec": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int],
     "fdbm_run_program": [ctypes.POINTER(Op), c_int],
 }
-EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc"])
+EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan"])
 
 
 def lib():
@@ -88,6 +89,8 @@ def lib():
         L.fdbm_version.restype = c_int
         L.fdbm_conv_kc.argtypes = [c_int]
         L.fdbm_conv_kc.restype = c_int
+        L.fdbm_conv_plan.argtypes = [c_i64, c_int, c_int] + [ctypes.POINTER(c_int)] * 3
+        L.fdbm_conv_plan.restype = c_int
         _lib = L
     return _lib
 
@@ -119,6 +122,12 @@ def conv_kc(code):
     return lib().fdbm_conv_kc(code)
 
 
+def conv_plan(M, cout, nk):
+    bm, bn, ks = c_int(), c_int(), c_int()
+    lib().fdbm_conv_plan(M, cout, nk, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(ks))
+    return bm.value, bn.value, ks.value
+
+
 def _dev_f32(w, device):
     return w.detach().to(device=device, dtype=torch.float32).contiguous()
 
@@ -146,8 +155,9 @@ def pc_predictor(x, s, y, z, wx, ws, wy, gd, dt):
     dev = x.device
     x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
     ws_ = [_dev_f32(w, dev) for w in (wx, ws, wy, gd)]
-    call("fdbm_pc_predictor", ptr(x_new), ptr(x_mean), ptr(x.contiguous()), ptr(s.contiguous()),
-         ptr(y.contiguous()), ptr(z.contiguous()), *[ptr(w) for w in ws_], float(dt), x.shape[0], x[0].numel())
+    ts_ = [v.contiguous() for v in (x, s, y, z)]          # held until the call returns
+    call("fdbm_pc_predictor", ptr(x_new), ptr(x_mean), *[ptr(v) for v in ts_], *[ptr(w) for w in ws_],
+         float(dt), x.shape[0], x[0].numel())
     return x_new, x_mean
 
 
@@ -155,8 +165,9 @@ def pc_corrector(x, s, y, noise, a, b, den, step, nscale):
     dev = x.device
     x_new, x_mean = torch.empty_like(x), torch.empty_like(x)
     ws_ = [_dev_f32(w, dev) for w in (a, b, den, step, nscale)]
-    call("fdbm_pc_corrector", ptr(x_new), ptr(x_mean), ptr(x.contiguous()), ptr(s.contiguous()),
-         ptr(y.contiguous()), ptr(noise.contiguous()), *[ptr(w) for w in ws_], x.shape[0], x[0].numel())
+    ts_ = [v.contiguous() for v in (x, s, y, noise)]
+    call("fdbm_pc_corrector", ptr(x_new), ptr(x_mean), *[ptr(v) for v in ts_], *[ptr(w) for w in ws_],
+         x.shape[0], x[0].numel())
     return x_new, x_mean
 
 
@@ -170,6 +181,7 @@ def upfirdn2d(inp, kernel, up=1, down=1, pad=(0, 0)):
     out_h = (H * up + pad[0] + pad[1] - kh) // down + 1
     out_w = (W * up + pad[0] + pad[1] - kw) // down + 1
     out = torch.empty(B, C, out_h, out_w, device=inp.device, dtype=torch.float32)
-    call("fdbm_upfirdn2d", ptr(out), ptr(inp.contiguous()), ptr(k), B * C, H, W, 1, kh, kw,
+    inp = inp.contiguous()
+    call("fdbm_upfirdn2d", ptr(out), ptr(inp), ptr(k), B * C, H, W, 1, kh, kw,
          up, up, down, down, pad[0], pad[1], pad[0], pad[1])
     return out

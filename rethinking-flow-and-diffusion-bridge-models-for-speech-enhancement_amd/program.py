@@ -163,12 +163,14 @@ class Program:
         self.esize = 2 if net.dtype == torch.bfloat16 else 4
         self.pool = Pool(self.dev)
         self.ops = []          # (opcode, iargs, fargs)
-        self.keep = []         # ctypes structs / tensors that must outlive the program
+        self.keep = []         # tensors that must outlive the program
+        self.keep_conv = []    # ConvArgs structs, one per conv op, in op order
+        self.splitk_ws = None
         self.macs = 0
         dev = self.dev
         self.x_in = torch.zeros(B, 1, F, T, dtype=torch.complex64, device=dev)
         self.y_in = torch.zeros(B, 1, F, T, dtype=torch.complex64, device=dev)
-        self.t_in = torch.ones(B, dtype=torch.float32, device=dev)
+        self.t_in = torch.zeros(B, dtype=torch.float32, device=dev)      # holds log t (host-evaluated)
         self.s_out = torch.zeros(B, 1, F, T, dtype=torch.complex64, device=dev)
         self._build()
         self._finalize()
@@ -191,29 +193,27 @@ class Program:
         self.ops.append((opcode, [int(v) for v in iargs], [float(v) for v in fargs]))
 
     def gn_stats(self, srcs, G):
-        """srcs: list of 1 or 2 Acts (virtual concat) -> mean_rstd buffer [B][G][2]."""
+        """srcs: list of 1 or 2 Acts (virtual concat) -> (partial sums buffer, nsplit, count);
+        the consumers (gn_apply / resample) finish the reduction themselves."""
         a0 = srcs[0]
         a1 = srcs[1] if len(srcs) > 1 else None
         HW = a0.H * a0.W
         C = a0.C + (a1.C if a1 else 0)
-        nsplit = max(1, min(HW, 256, (HW * C) // 32768))
+        nsplit = max(1, min(HW, 64, (HW * C) // 32768))
         partial = self.new_f32(self.B * nsplit * G * 2)
-        mr = self.new_f32(self.B * G * 2)
         self.emit(hip.OP_GN_STATS, [partial.data_ptr(), a0.ptr, a0.C, a1.ptr if a1 else 0,
                                     a1.C if a1 else 0, self.B, HW, G, nsplit, hip.dt_code(a0.dtype)])
-        self.emit(hip.OP_GN_FINALIZE, [mr.data_ptr(), partial.data_ptr(), self.B, nsplit, G,
-                                       HW * (C // G)], [1e-6])
-        self.pool.put(partial)
-        return mr
+        return (partial, nsplit, HW * (C // G))
 
-    def gn_apply(self, srcs, mr, gamma, beta, G, silu):
+    def gn_apply(self, srcs, st, gamma, beta, G, silu):
         a0 = srcs[0]
         a1 = srcs[1] if len(srcs) > 1 else None
         C = a0.C + (a1.C if a1 else 0)
         out = self.new_act(a0.H, a0.W, C)
+        partial, nsplit, count = st
         self.emit(hip.OP_GN_APPLY, [out.ptr, a0.ptr, a0.C, a1.ptr if a1 else 0, a1.C if a1 else 0,
-                                    mr.data_ptr(), gamma.data_ptr(), beta.data_ptr(), self.B,
-                                    a0.H * a0.W, G, 1 if silu else 0, self.dtc])
+                                    partial.data_ptr(), nsplit, count, gamma.data_ptr(), beta.data_ptr(),
+                                    self.B, a0.H * a0.W, G, 1 if silu else 0, self.dtc], [1e-6])
         return out
 
     def conv(self, segs, wpack, cout_pad, cout, bias, out_dtype=None, tbias=None, tb_stride=0,
@@ -237,19 +237,29 @@ class Program:
         ca.B, ca.H, ca.W, ca.Cout, ca.CoutPad = self.B, a0.H, a0.W, cout, cout_pad
         ca.dt_in = hip.dt_code(a0.dtype)
         ca.dt_out = hip.dt_code(out.dtype)
-        self.keep.append(ca)
+        kc = hip.conv_kc(ca.dt_in)
+        nk = sum(taps * ((cin + kc - 1) // kc) for (_, _, cin, taps) in segs)
+        _, _, ks = hip.conv_plan(a0.M, cout, nk)
+        if ks > 1:                      # split-K slabs: one shared scratch, ops run in order
+            need = ks * a0.M * cout * 4
+            if self.splitk_ws is None or self.splitk_ws.numel() < need:
+                self.splitk_ws = torch.empty(max(need, 8 << 20), dtype=torch.uint8, device=self.dev)
+                self.keep.append(self.splitk_ws)
+            ca.workspace, ca.workspace_bytes = self.splitk_ws.data_ptr(), self.splitk_ws.numel()
+        self.keep_conv.append(ca)
         self.emit(hip.OP_CONV, [ctypes.addressof(ca)])
         return out
 
-    def resample(self, a, up, mr=None, gamma=None, beta=None, G=0, want_plain=True):
+    def resample(self, a, up, st=None, gamma=None, beta=None, G=0, want_plain=True):
         OH, OW = (2 * a.H, 2 * a.W) if up else (a.H // 2, a.W // 2)
         plain = self.new_act(OH, OW, a.C, a.dtype) if want_plain else None
-        act = self.new_act(OH, OW, a.C, a.dtype) if mr is not None else None
+        act = self.new_act(OH, OW, a.C, a.dtype) if st is not None else None
+        partial, nsplit, count = st if st is not None else (None, 0, 0)
         self.emit(hip.OP_RESAMPLE, [plain.ptr if plain else 0, act.ptr if act else 0, a.ptr,
-                                    mr.data_ptr() if mr is not None else 0,
+                                    partial.data_ptr() if partial is not None else 0, nsplit, count,
                                     gamma.data_ptr() if gamma is not None else 0,
                                     beta.data_ptr() if beta is not None else 0,
-                                    self.B, a.H, a.W, a.C, G, 1 if up else 0, hip.dt_code(a.dtype)])
+                                    self.B, a.H, a.W, a.C, G, 1 if up else 0, hip.dt_code(a.dtype)], [1e-6])
         return plain, act
 
     # ---- blocks ------------------------------------------------------------------------
@@ -267,14 +277,14 @@ class Program:
         else:
             a0 = self.gn_apply(srcs, mr0, W["gn0_w"], W["gn0_b"], G0, True)
             short_srcs = srcs
-        self.pool.put(mr0)
+        self.pool.put(mr0[0])
         tb = self.net.dense_out_ptr(self, mod.idx)
         h1 = self.conv([(a0, 0, in_ch, 9)], W["conv0"], W["conv0_pad"], out_ch, W["conv0_b"],
                        tbias=tb, tb_stride=self.net.dense_rows)
         self.free_act(a0)
         mr1 = self.gn_stats([h1], G1)
         a1 = self.gn_apply([h1], mr1, W["gn1_w"], W["gn1_b"], G1, True)
-        self.pool.put(mr1)
+        self.pool.put(mr1[0])
         self.free_act(h1)
         segs = [(a1, 0, out_ch, 9)]
         res = None
@@ -296,7 +306,7 @@ class Program:
         G = gn_groups(C)
         mr = self.gn_stats([x], G)
         a = self.gn_apply([x], mr, W["gn_w"], W["gn_b"], G, False)
-        self.pool.put(mr)
+        self.pool.put(mr[0])
         qkv = self.conv([(a, 0, C, 1)], W["qkv"], W["qkv_pad"], 3 * C, W["qkv_b"])
         self.free_act(a)
         N = x.H * x.W
@@ -394,7 +404,7 @@ class Program:
             gw, hw = net.w[gnm.idx], net.w[head.idx]
             mr = self.gn_stats([h], G)
             a = self.gn_apply([h], mr, gw["w"], gw["b"], G, True)
-            self.pool.put(mr)
+            self.pool.put(mr[0])
             up_pyr = None
             if pyramid is not None:
                 up_pyr, _ = self.resample(pyramid, True)

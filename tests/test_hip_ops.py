@@ -28,6 +28,11 @@ def nchw(x):
     return x.float().cpu().permute(0, 3, 1, 2).contiguous()
 
 
+def close(out, ref, tol):
+    """|out - ref| <= tol * (1 + |ref|) everywhere (bf16 outputs carry 2^-9 relative rounding)."""
+    return bool(((out - ref).abs() <= tol * (1 + ref.abs())).all())
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -131,9 +136,18 @@ def test_groupnorm(dtype, tol, C0, C1, G):
     rstd = 1 / torch.sqrt(xr.var(-1, unbiased=False) + 1e-6)
     assert ((mr[:, :, 1].cpu() - rstd) / rstd).abs().max() < 1e-5
     out = torch.empty(B, H, W, C0 + C1, device=DEV, dtype=dtype)
-    hip.call("fdbm_gn_apply", hip.ptr(out), hip.ptr(d0), C0, hip.ptr(d1), C1, hip.ptr(mr), hip.ptr(gamma.to(DEV)),
-             hip.ptr(beta.to(DEV)), B, H * W, G, 1, hip.dt_code(dtype))
+    gd, bd = gamma.to(DEV), beta.to(DEV)        # keep device copies alive across the call
+    hip.call("fdbm_gn_apply", hip.ptr(out), hip.ptr(d0), C0, hip.ptr(d1), C1, hip.ptr(mr), 0, 0, 1e-6, hip.ptr(gd),
+             hip.ptr(bd), B, H * W, G, 1, hip.dt_code(dtype))
     assert (nchw(out) - ref).abs().max() < tol
+    # same thing straight from the partial sums (what the recorded programs do)
+    nsplit = 5
+    partial = torch.empty(B * nsplit * G * 2, device=DEV)
+    hip.call("fdbm_gn_stats", hip.ptr(partial), hip.ptr(d0), C0, hip.ptr(d1), C1, B, H * W, G, nsplit, hip.dt_code(dtype))
+    out2 = torch.empty_like(out)
+    hip.call("fdbm_gn_apply", hip.ptr(out2), hip.ptr(d0), C0, hip.ptr(d1), C1, hip.ptr(partial), nsplit,
+             H * W * ((C0 + C1) // G), 1e-6, hip.ptr(gd), hip.ptr(bd), B, H * W, G, 1, hip.dt_code(dtype))
+    assert (nchw(out2) - ref).abs().max() < tol
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 4e-2)])
@@ -151,8 +165,9 @@ def test_resample2x(dtype, tol, up):
     OH, OW = (2 * H, 2 * W) if up else (H // 2, W // 2)
     o_plain = torch.empty(B, OH, OW, C, device=DEV, dtype=dtype)
     o_act = torch.empty_like(o_plain)
-    hip.call("fdbm_resample2x", hip.ptr(o_plain), hip.ptr(o_act), hip.ptr(d), hip.ptr(mr), hip.ptr(gamma.to(DEV)),
-             hip.ptr(beta.to(DEV)), B, H, W, C, G, int(up), hip.dt_code(dtype))
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    hip.call("fdbm_resample2x", hip.ptr(o_plain), hip.ptr(o_act), hip.ptr(d), hip.ptr(mr), 0, 0, 1e-6, hip.ptr(gd),
+             hip.ptr(bd), B, H, W, C, G, int(up), hip.dt_code(dtype))
     assert (nchw(o_plain) - ref_plain).abs().max() < tol
     assert (nchw(o_act) - ref_act).abs().max() < tol
     # plain only, 4-channel f32 pyramid flavour
@@ -160,11 +175,11 @@ def test_resample2x(dtype, tol, up):
         p = rnd(B, 4, H, W, seed=6)
         dp = nhwc(p)
         o = torch.empty(B, OH, OW, 4, device=DEV)
-        hip.call("fdbm_resample2x", hip.ptr(o), 0, hip.ptr(dp), 0, 0, 0, B, H, W, 4, 0, int(up), hip.F32)
+        hip.call("fdbm_resample2x", hip.ptr(o), 0, hip.ptr(dp), 0, 0, 0, 0.0, 0, 0, B, H, W, 4, 0, int(up), hip.F32)
         assert (nchw(o) - fn(p)).abs().max() < 1e-6
 
 
-def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=None, scale=1.0):
+def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=None, scale=1.0, splitk=False):
     """segs_nchw: list of (x NCHW cpu tensor, taps); weights: list of W [Cout, cin, k, k] per seg."""
     out_dtype = out_dtype or dtype
     kc = hip.conv_kc(hip.dt_code(dtype))
@@ -191,6 +206,9 @@ def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=No
     ca.out = out.data_ptr()
     ca.B, ca.H, ca.W, ca.Cout, ca.CoutPad = B, H, W, cout, cpad
     ca.dt_in, ca.dt_out = hip.dt_code(dtype), hip.dt_code(out_dtype)
+    if splitk:
+        ws = torch.empty(8 << 20, dtype=torch.uint8, device=DEV)
+        ca.workspace, ca.workspace_bytes = ws.data_ptr(), ws.numel()
     hip.call("fdbm_conv_igemm", ca)
     torch.cuda.synchronize()
     return nchw(out), keep, rd
@@ -207,12 +225,15 @@ CONV_CASES = [
     ("res_tbias", 2, 8, 8, [64], 64, 9, dict(res=True, tbias=True)),
     ("shortcut", 1, 8, 8, [128], 256, 9, dict(shortcut=[256, 128])),
     ("ragged_w", 1, 6, 10, [32], 32, 9, {}),
+    ("big_m", 1, 64, 128, [64], 128, 9, {}),
+    ("mid_m_256", 1, 32, 32, [256], 256, 9, dict(res=True)),
 ]
 
 
+@pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_igemm(case, dtype):
+def test_conv_igemm(case, dtype, splitk):
     name, B, H, W, cins, cout, taps, extra = case
     k = 3 if taps == 9 else 1
     xs = [rnd(B, c, H, W, seed=10 + i) for i, c in enumerate(cins)]
@@ -243,7 +264,7 @@ def test_conv_igemm(case, dtype):
         r = rnd(B, cout, H, W, seed=71)
         ref = ref + r
         kw.update(res=r, scale=1.0)
-    out, _, _ = run_conv(segs, weights, bias, dtype, out_dtype=out_dtype, **kw)
+    out, _, _ = run_conv(segs, weights, bias, dtype, out_dtype=out_dtype, splitk=splitk, **kw)
     assert not torch.isnan(out).any()
     err = (out - ref).abs().max().item()
     tol = 2e-5 if dtype == torch.float32 else (2e-2 if out_dtype == torch.bfloat16 else 2e-3)
@@ -260,7 +281,8 @@ def test_attention(dtype, tol, N, C):
     w = torch.softmax(torch.einsum("bic,bjc->bij", q, k) * (C ** -0.5), dim=-1)
     ref = torch.einsum("bij,bjc->bic", w, v)
     out = torch.empty(B, N, C, device=DEV, dtype=dtype)
-    hip.call("fdbm_attention", hip.ptr(out), hip.ptr(qkv.to(DEV)), B, N, C, hip.dt_code(dtype))
+    qd = qkv.to(DEV)
+    hip.call("fdbm_attention", hip.ptr(out), hip.ptr(qd), B, N, C, hip.dt_code(dtype))
     assert (out.float().cpu() - ref).abs().max() < tol
 
 
@@ -276,10 +298,9 @@ def test_temb_and_dense():
     out = torch.empty(B, 4 * nf, device=DEV)
     scratch = torch.empty(B, 4 * nf, device=DEV)
     d = lambda x: x.to(DEV).contiguous()
-    keep = [d(x) for x in (t, fw, w1, b1, w2, b2)]
+    keep = [d(x) for x in (torch.log(t), fw, w1, b1, w2, b2)]
     hip.call("fdbm_temb", hip.ptr(out), *[hip.ptr(x) for x in keep], hip.ptr(scratch), B, nf)
-    assert (out.cpu() - ref).abs().max() < 2e-4       # arguments up to ~2000 rad at t = 1e-4
-    assert (out.cpu()[:2] - ref[:2]).abs().max() < 2e-5
+    assert (out.cpu() - ref).abs().max() < 2e-6       # same fp32 argument -> sin/cos agree to ~1 ulp
     R = 200
     wd, bd = rnd(R, 4 * nf, seed=95) / math.sqrt(4 * nf), rnd(R, seed=96)
     o2 = torch.empty(B, R, device=DEV)
@@ -288,24 +309,26 @@ def test_temb_and_dense():
     assert (o2.cpu() - F.linear(out.cpu(), wd, bd)).abs().max() < 1e-5
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 8e-3)])
 def test_stem_pack_unpack_combine(dtype, tol):
     B, Fq, T, nf = 2, 257, 16, 64
     x, y = crnd(B, 1, Fq, T, seed=1), crnd(B, 1, Fq, T, seed=2)
     inp = torch.empty(B, 256, T, 4, device=DEV)
-    hip.call("fdbm_pack_input", hip.ptr(inp), hip.ptr(x.to(DEV)), hip.ptr(y.to(DEV)), B, Fq, 256, T)
+    xd, yd = x.to(DEV), y.to(DEV)
+    hip.call("fdbm_pack_input", hip.ptr(inp), hip.ptr(xd), hip.ptr(yd), B, Fq, 256, T)
     ref_in = torch.cat((x.real, x.imag, y.real, y.imag), 1)[:, :, :256]
     assert torch.equal(nchw(inp), ref_in)
     w, b = rnd(nf, 4, 3, 3, seed=3) / 6, rnd(nf, seed=4) * 0.1
     out = torch.empty(B, 256, T, nf, device=DEV, dtype=dtype)
-    wd = w.permute(0, 2, 3, 1).contiguous().to(DEV)
-    hip.call("fdbm_conv_stem", hip.ptr(out), hip.ptr(inp), hip.ptr(wd), hip.ptr(b.to(DEV)), B, 256, T, nf, hip.dt_code(dtype))
-    assert (nchw(out) - F.conv2d(ref_in, w, b, padding=1)).abs().max() < tol
+    wd, bdv = w.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV)
+    hip.call("fdbm_conv_stem", hip.ptr(out), hip.ptr(inp), hip.ptr(wd), hip.ptr(bdv), B, 256, T, nf, hip.dt_code(dtype))
+    assert close(nchw(out), F.conv2d(ref_in, w, b, padding=1), tol)
     # output layer + Nyquist row
     pyr = rnd(B, 4, 256, T, seed=5)
     ow, ob = rnd(2, 4, seed=6), rnd(2, seed=7)
     s = torch.empty(B, 1, Fq, T, dtype=torch.complex64, device=DEV)
-    hip.call("fdbm_unpack_output", hip.ptr(s), hip.ptr(nhwc(pyr)), hip.ptr(ow.to(DEV)), hip.ptr(ob.to(DEV)), B, Fq, 256, T)
+    pd, owd, obd = nhwc(pyr), ow.to(DEV), ob.to(DEV)
+    hip.call("fdbm_unpack_output", hip.ptr(s), hip.ptr(pd), hip.ptr(owd), hip.ptr(obd), B, Fq, 256, T)
     r = F.conv2d(pyr, ow[:, :, None, None], ob)
     ref = torch.cat((torch.complex(r[:, 0], r[:, 1])[:, None], torch.zeros(B, 1, 1, T, dtype=torch.complex64)), 2)
     assert (s.cpu() - ref).abs().max() < 1e-6
@@ -314,9 +337,10 @@ def test_stem_pack_unpack_combine(dtype, tol):
     h, p = rnd(B, C, 8, 8, seed=8), rnd(B, 4, 8, 8, seed=9)
     cw, cb = rnd(C, 4, seed=10), rnd(C, seed=11)
     hd = nhwc(h, dtype)
-    hip.call("fdbm_combine", hip.ptr(hd), hip.ptr(hd), hip.ptr(nhwc(p)), hip.ptr(cw.to(DEV)), hip.ptr(cb.to(DEV)), B * 64, C, hip.dt_code(dtype))
+    pd2, cwd, cbd = nhwc(p), cw.to(DEV), cb.to(DEV)
+    hip.call("fdbm_combine", hip.ptr(hd), hip.ptr(hd), hip.ptr(pd2), hip.ptr(cwd), hip.ptr(cbd), B * 64, C, hip.dt_code(dtype))
     ref = F.conv2d(p, cw[:, :, None, None], cb) + h.to(dtype).float()
-    assert (nchw(hd) - ref).abs().max() < tol
+    assert close(nchw(hd), ref, tol)
 
 
 @pytest.mark.parametrize("tag,n_fft,hop,window", [("512", 512, 256, "sqrthann"), ("510", 510, 128, "hann")])
@@ -334,6 +358,11 @@ def test_frontend(golden, tag, n_fft, hop, window):
     assert (Y0.cpu() - torch.from_numpy(g["pad_zero"])).abs().max() < 2e-5
     x = fe.to_audio(torch.from_numpy(g["spec_fwd"]).to(DEV), wave.shape[-1])
     assert (x.cpu() - torch.from_numpy(g["istft"])).abs().max() < 5e-6
-    # round trip through the padded spectrogram (what the drivers do)
-    x2 = fe.to_audio(Y[0, 0] if Y.dim() == 4 else Y, wave.shape[-1])
-    assert (x2.cpu() - wave.cpu()).abs().max() < 1e-5
+    # the padded spectrogram back to audio (what the drivers do): torch.istft, like the oracle,
+    # overlap-adds ALL columns, so reflected pad frames reach the last partial frame
+    from oracle import frontend as ofe
+    x2 = fe.to_audio(Y[:, 0], wave.shape[-1])
+    ref2 = ofe.istft(ofe.spec_back(Y[:, 0].cpu()), wave.shape[-1], n_fft=n_fft, hop=hop, window=window)
+    assert (x2.cpu() - ref2).abs().max() < 1e-5
+    n_safe = (wave.shape[-1] // hop - 1) * hop        # samples no pad frame touches
+    assert (x2.cpu()[..., :n_safe] - wave.cpu()[..., :n_safe]).abs().max() < 1e-5

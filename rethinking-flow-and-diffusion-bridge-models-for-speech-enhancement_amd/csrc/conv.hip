@@ -19,6 +19,8 @@
 // to the other LDS buffer after the MFMAs of the step before them; one barrier per k-step.
 // Small-M layers (the 4x4 ... 32x32 levels at batch 1) split the k-steps over grid.z and a
 // second kernel sums the fp32 slabs and applies the epilogue (weights are streamed once).
+#include <type_traits>
+
 #include "common.h"
 
 struct ConvParams {
@@ -67,6 +69,10 @@ template <> struct OutVec<bf16_t> {
   }
 };
 
+// p.seg[ks] with a run-time ks makes the compiler copy the whole kernel argument to scratch
+// and index it there; chains of wave-uniform selects on constant indices stay in SGPRs.
+#define SEG_FIELD(p, ks, f) ((ks) == 0 ? (p).seg[0].f : (ks) == 1 ? (p).seg[1].f : (ks) == 2 ? (p).seg[2].f : (p).seg[3].f)
+
 template <typename T, typename TO, int BM, int BN>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   constexpr int KC = 128 / (int)sizeof(T);   // elements per k-step row
@@ -113,57 +119,63 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     pbase[i] = b * HW;
   }
 
-  uint4 areg[2][AROWS], wreg[2][WROWS];
+  uint4 areg0[AROWS], wreg0[WROWS], areg1[AROWS], wreg1[WROWS];   // two named register sets
   int ks = 0, ktap = 0, kc = 0;     // segment / tap / chunk of the NEXT k-step to load
   for (int i = 0; i < kbeg; ++i) {  // advance the cursor to this block's first k-step
-    const fdbm_conv_seg& sg = p.seg[ks];
-    const int nchunks = (sg.cin + KC - 1) / KC;
+    const int nchunks = (SEG_FIELD(p, ks, cin) + KC - 1) / KC;
     if (++kc == nchunks) {
       kc = 0;
-      if (++ktap == sg.taps) { ktap = 0; ++ks; }
+      if (++ktap == SEG_FIELD(p, ks, taps)) { ktap = 0; ++ks; }
     }
   }
 
   // Loads are unconditional (clamped address, then a select): a branch around each load makes
   // hipcc wait for every load separately - one L2 round trip per row instead of one per k-step.
-  auto load_regs = [&](uint4* ar, uint4* wr, int kidx) {
-    const fdbm_conv_seg& sg = p.seg[ks];
-    const int dy = sg.taps == 9 ? ktap / 3 - 1 : 0;
-    const int dx = sg.taps == 9 ? ktap % 3 - 1 : 0;
-    const int cvalid = min(KC, sg.cin - kc * KC);
+  auto load_regs = [&](auto SET, int kidx) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    const void* sg_src = SEG_FIELD(p, ks, src);
+    const int sg_C = SEG_FIELD(p, ks, C), sg_coff = SEG_FIELD(p, ks, coff);
+    const int sg_cin = SEG_FIELD(p, ks, cin), sg_taps = SEG_FIELD(p, ks, taps);
+    const int dy = sg_taps == 9 ? ktap / 3 - 1 : 0;
+    const int dx = sg_taps == 9 ? ktap % 3 - 1 : 0;
+    const int cvalid = min(KC, sg_cin - kc * KC);
     const bool cok = lchunk * VW < cvalid;
-    const T* src = reinterpret_cast<const T*>(sg.src) + sg.coff + (cok ? kc * KC + lchunk * VW : 0);
+    const T* src = reinterpret_cast<const T*>(sg_src) + sg_coff + (cok ? kc * KC + lchunk * VW : 0);
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int iy = py[i] + dy, ix = px[i] + dx;
       const bool ok = cok && pval[i] && iy >= 0 && iy < H && ix >= 0 && ix < W;
       const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
-      uint4 v = *reinterpret_cast<const uint4*>(src + (pbase[i] + (int64_t)iyc * W + ixc) * sg.C);
+      uint4 v = *reinterpret_cast<const uint4*>(src + (pbase[i] + (int64_t)iyc * W + ixc) * sg_C);
       if (!ok) v = uint4{0u, 0u, 0u, 0u};
-      ar[i] = v;
+      if constexpr (S == 0) areg0[i] = v; else areg1[i] = v;
     }
     const T* wp = reinterpret_cast<const T*>(p.w) + ((int64_t)kidx * p.CoutPad + n0 + lrow) * KC + lchunk * VW;
 #pragma unroll
-    for (int i = 0; i < WROWS; ++i) wr[i] = *reinterpret_cast<const uint4*>(wp + (int64_t)32 * i * KC);
-    const int nchunks = (sg.cin + KC - 1) / KC;
+    for (int i = 0; i < WROWS; ++i) {
+      const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)32 * i * KC);
+      if constexpr (S == 0) wreg0[i] = v; else wreg1[i] = v;
+    }
+    const int nchunks = (sg_cin + KC - 1) / KC;
     if (++kc == nchunks) {
       kc = 0;
-      if (++ktap == sg.taps) { ktap = 0; ++ks; }
+      if (++ktap == sg_taps) { ktap = 0; ++ks; }
     }
   };
 
-  auto write_lds = [&](int buf, const uint4* ar, const uint4* wr) {
+  auto write_lds = [&](auto SET, int buf) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
     unsigned char* A = smem + buf * BUF;
     unsigned char* Wt = A + BM * 128;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int row = lrow + 32 * i;
-      *reinterpret_cast<uint4*>(A + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = ar[i];
+      *reinterpret_cast<uint4*>(A + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = (S == 0 ? areg0[i] : areg1[i]);
     }
 #pragma unroll
     for (int i = 0; i < WROWS; ++i) {
       const int row = lrow + 32 * i;
-      *reinterpret_cast<uint4*>(Wt + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = wr[i];
+      *reinterpret_cast<uint4*>(Wt + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = (S == 0 ? wreg0[i] : wreg1[i]);
     }
   };
 
@@ -176,7 +188,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   const int frow = lane & 15;
   const int fk = lane >> 4;
 
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     const unsigned char* A = smem + buf * BUF;
     const unsigned char* Wt = A + BM * 128;
     if constexpr (!F32) {
@@ -244,20 +256,22 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   // ---- main loop: loads run two k-steps ahead of the MFMAs ------------------------------
   //   iteration t:  issue loads of step t+2 -> regs[t&1] ; MFMAs on LDS buf[t&1] ;
   //                 regs[(t+1)&1] (issued one iteration ago) -> LDS buf[(t+1)&1] ; barrier
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
   if (nloc > 0) {
-    load_regs(areg[0], wreg[0], kbeg);
-    if (nloc > 1) load_regs(areg[1], wreg[1], kbeg + 1);
-    write_lds(0, areg[0], wreg[0]);
+    load_regs(S0{}, kbeg);
+    if (nloc > 1) load_regs(S1{}, kbeg + 1);
+    write_lds(S0{}, 0);
     __syncthreads();
     int t = 0;
     for (; t + 1 < nloc; t += 2) {
-      if (t + 2 < nloc) load_regs(areg[0], wreg[0], kbeg + t + 2);
+      if (t + 2 < nloc) load_regs(S0{}, kbeg + t + 2);
       compute(0);
-      write_lds(1, areg[1], wreg[1]);
+      write_lds(S1{}, 1);
       __syncthreads();
-      if (t + 3 < nloc) load_regs(areg[1], wreg[1], kbeg + t + 3);
+      if (t + 3 < nloc) load_regs(S1{}, kbeg + t + 3);
       compute(1);
-      if (t + 2 < nloc) write_lds(0, areg[0], wreg[0]);
+      if (t + 2 < nloc) write_lds(S0{}, 0);
       __syncthreads();
     }
     if (t < nloc) compute(0);

@@ -155,6 +155,31 @@ typedef struct {
   int32_t dt_out;       /* FDBM_F32 | FDBM_BF16 (f32 out with bf16 in is allowed)   */
   void* workspace;      /* optional split-K scratch (fp32 slabs) or NULL            */
   int64_t workspace_bytes;
+  /* optional GroupNorm(+SiLU) prologue: act(gn(x)) is applied to the segments selected by
+   * seg_gn_mask (in order they form the normalised, virtually concatenated tensor of gn_C
+   * channels) while they are staged, zero padding after the activation - i.e.
+   * conv(act(GroupNorm(cat(...)))) of layerspp.py:243-266 in one kernel.  gn_sums holds
+   * (sum, sumsq) per (image, split, group): [B][gn_nsplit][gn_G][2]. */
+  const float* gn_sums;
+  const float* gn_gamma;
+  const float* gn_beta;
+  int32_t gn_nsplit, gn_G, gn_C, gn_silu;
+  int64_t gn_count;     /* elements per (image, group)                              */
+  float gn_eps;
+  uint32_t seg_gn_mask;
+  /* optional Combine('sum') epilogue (layerspp.py:52-57): out += comb_b[n] + comb_w[n][0..3] .
+   * comb_pyr[m][0..3]  (f32 [M][4], f32 [Cout][4], f32 [Cout]) */
+  const float* comb_pyr;
+  const float* comb_w;
+  const float* comb_b;
+  /* optional: accumulate (sum, sumsq) of the STORED output per (image, group of Cout/stat_G
+   * channels) into stat_out[B][stat_nsplit][stat_G][2] with atomics (caller zeroes it; a block
+   * adds into row blockIdx.x % stat_nsplit so the atomics do not all hit one address) - the
+   * statistics the consuming GroupNorm needs, without another pass over the tensor; same layout
+   * as fdbm_gn_stats' partial sums. */
+  float* stat_out;
+  int32_t stat_G;
+  int32_t stat_nsplit;
 } fdbm_conv_args;
 
 int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream);
@@ -219,7 +244,9 @@ typedef struct {
 #define FDBM_OP_TEMB 11
 #define FDBM_OP_DENSE 12
 #define FDBM_OP_UPDATE 13
+#define FDBM_OP_MEMSET 14      /* iarg: ptr, bytes (hipMemsetAsync to 0) */
 
+int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream);
 int fdbm_run_program(const fdbm_op* ops_host, int n_ops, void* stream);
 
 #ifdef __cplusplus

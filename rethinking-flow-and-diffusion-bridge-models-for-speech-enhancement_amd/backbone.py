@@ -41,7 +41,7 @@ class HipNCSNpp:
         return parser
 
     def __init__(self, nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,),
-                 dtype=torch.bfloat16, device=None, state=None, seed=0, **unused_kwargs):
+                 dtype=torch.bfloat16, device=None, state=None, seed=0, fused=None, **unused_kwargs):
         if not torch.cuda.is_available():
             raise RuntimeError("HipNCSNpp needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -50,6 +50,11 @@ class HipNCSNpp:
                          attn_resolutions=attn_resolutions)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.dtype = dtype
+        # fused mode: GroupNorm statistics come from the producing conv's epilogue (fp32 atomics,
+        # run-to-run order) and GroupNorm+SiLU is applied inside the consuming conv where that is
+        # cheap.  Default: on for the bf16 throughput mode, off for the bit-reproducible f32
+        # parity mode.
+        self.fused = (dtype == torch.bfloat16) if fused is None else bool(fused)
         self._programs = {}
         self._graphs = {}
         self.sample_graph = None                    # installed by enable_graphs()
@@ -115,7 +120,13 @@ class HipNCSNpp:
                                      proj=proj, proj_pad=ppad, proj_b=g(p + ".NIN_3.b"))
             elif m.kind == "resblock":
                 has2 = (p + ".Conv_2.weight") in shapes
-                c0, c0pad = pack_conv_weight([(g(p + ".Conv_0.weight"), 9)], kc, dt, dev)
+                # one K segment per source tensor of the (virtual) concat
+                w0 = g(p + ".Conv_0.weight")
+                segs0, off = [], 0
+                for c in self._concat_split(m):
+                    segs0.append((w0[:, off:off + c], 9))
+                    off += c
+                c0, c0pad = pack_conv_weight(segs0, kc, dt, dev)
                 segs = [(g(p + ".Conv_1.weight"), 9)]
                 b1 = g(p + ".Conv_1.bias")
                 if has2:

@@ -23,22 +23,6 @@
 
 #include "common.h"
 
-struct ConvParams {
-  fdbm_conv_seg seg[FDBM_MAX_SEG];
-  int nseg;
-  const void* w;
-  const float* bias;
-  const float* tbias;
-  int tbias_stride;
-  const void* res;
-  float scale;
-  void* out;
-  int B, H, W, Cout, CoutPad;
-  int nk;
-  int ksplit;       // grid.z: k-steps are split over this many workgroups
-  float* partial;   // fp32 slabs [ksplit][M][Cout] when ksplit > 1
-};
-
 template <typename T> struct Mfma;
 template <> struct Mfma<bf16_t> {
   __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& acc) {
@@ -69,11 +53,93 @@ template <> struct OutVec<bf16_t> {
   }
 };
 
+struct ConvParams {
+  fdbm_conv_seg seg[FDBM_MAX_SEG];
+  int nseg;
+  const void* w;
+  const float* bias;
+  const float* tbias;
+  int tbias_stride;
+  const void* res;
+  float scale;
+  void* out;
+  int B, H, W, Cout, CoutPad;
+  int nk;
+  int ksplit;       // grid.z: k-steps are split over this many workgroups
+  float* partial;   // fp32 slabs [ksplit][M][Cout] when ksplit > 1
+  // GroupNorm(+SiLU) applied to the A operand while it is staged (segments with seg_gn >= 0;
+  // seg_gn = channel offset of the segment inside the normalised, virtually concatenated input)
+  const float* gn_sums;     // [B][gn_nsplit][gn_G][2] (sum, sumsq) or NULL
+  const float* gn_gamma;
+  const float* gn_beta;
+  int gn_nsplit, gn_G, gn_C, gn_silu;
+  double gn_inv_count;
+  float gn_eps;
+  int seg_gn[FDBM_MAX_SEG];
+  // Combine('sum') folded into the epilogue: out += comb_b[n] + comb_w[n][0..3] . pyr[m][0..3]
+  const float* comb_pyr;
+  const float* comb_w;
+  const float* comb_b;
+  // (sum, sumsq) of the stored output per (image, group of Cout/stat_G channels), accumulated
+  // with atomics into stat_out[B][stat_G][2] for the GroupNorm that consumes this tensor
+  float* stat_out;
+  int stat_G;
+  int stat_nsplit;   // stat_out is [B][stat_nsplit][stat_G][2]; a block adds into split blockIdx.x % nsplit
+};
+
+// sum over the 16 lanes of a DPP row (= the 16 pixels of an MFMA m-tile), every lane gets it:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - four VALU adds.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
+#define CONV_MAX_NB 4          // images one M tile may touch when a GN prologue / stats are on
+#define CONV_GN_MAXC 512
+
+// final value of 4 consecutive output channels of pixel m: bias, time-embedding bias, residual,
+// scale, Combine; stores and returns the stored (rounded) values in v.
+template <typename TO>
+__device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int64_t m, int64_t b, int n, float* v) {
+  const int Cout = p.Cout;
+  if (p.bias) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+  }
+  if (p.tbias) {
+    const f32x4 tv = *reinterpret_cast<const f32x4*>(p.tbias + b * p.tbias_stride + n);
+    v[0] += tv[0]; v[1] += tv[1]; v[2] += tv[2]; v[3] += tv[3];
+  }
+  if (p.res) {
+    float r[4];
+    OutVec<TO>::load(reinterpret_cast<const TO*>(p.res) + m * Cout + n, r);
+    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+  }
+  v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale;
+  if (p.comb_pyr) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(p.comb_pyr + m * 4);
+    const f32x4 cb = *reinterpret_cast<const f32x4*>(p.comb_b + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(p.comb_w + (int64_t)(n + r) * 4);
+      v[r] += cb[r] + (((w[0] * q[0] + w[1] * q[1]) + w[2] * q[2]) + w[3] * q[3]);
+    }
+  }
+  OutVec<TO>::store(reinterpret_cast<TO*>(p.out) + m * Cout + n, v);
+  if constexpr (sizeof(TO) == 2) {     // statistics are those of the STORED tensor
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (float)(bf16_t)v[r];
+  }
+}
+
 // p.seg[ks] with a run-time ks makes the compiler copy the whole kernel argument to scratch
 // and index it there; chains of wave-uniform selects on constant indices stay in SGPRs.
 #define SEG_FIELD(p, ks, f) ((ks) == 0 ? (p).seg[0].f : (ks) == 1 ? (p).seg[1].f : (ks) == 2 ? (p).seg[2].f : (p).seg[3].f)
 
-template <typename T, typename TO, int BM, int BN>
+template <typename T, typename TO, int BM, int BN, bool GNP>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   constexpr int KC = 128 / (int)sizeof(T);   // elements per k-step row
   constexpr int VW = 16 / (int)sizeof(T);    // elements per 16-byte chunk
@@ -119,7 +185,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     pbase[i] = b * HW;
   }
 
+  // ---- GroupNorm prologue table + output-statistics scratch (after the two LDS buffers) ----
+  float2* s_gn = reinterpret_cast<float2*>(smem + 2 * BUF);                  // [nb][gn_C] {scale, shift}
+  float* s_stat = reinterpret_cast<float*>(smem + 2 * BUF + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0));  // [nb][32][2]
+  const int b0 = (int)(m0 / HW);
+  int pbl[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) pbl[i] = (int)(pbase[i] / HW) - b0;
+  if (p.stat_out) {
+    for (int i = tid; i < CONV_MAX_NB * 64; i += 256) s_stat[i] = 0.f;
+  }
+  __syncthreads();
+
   uint4 areg0[AROWS], wreg0[WROWS], areg1[AROWS], wreg1[WROWS];   // two named register sets
+  unsigned okm0 = 0, okm1 = 0;      // per set: which rows are real (in-image, in-range) data
+  int gcb0 = -1, gcb1 = -1;         // per set: GN channel of this thread's chunk, or -1
   int ks = 0, ktap = 0, kc = 0;     // segment / tap / chunk of the NEXT k-step to load
   for (int i = 0; i < kbeg; ++i) {  // advance the cursor to this block's first k-step
     const int nchunks = (SEG_FIELD(p, ks, cin) + KC - 1) / KC;
@@ -141,14 +221,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     const int cvalid = min(KC, sg_cin - kc * KC);
     const bool cok = lchunk * VW < cvalid;
     const T* src = reinterpret_cast<const T*>(sg_src) + sg_coff + (cok ? kc * KC + lchunk * VW : 0);
+    unsigned okm = 0;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int iy = py[i] + dy, ix = px[i] + dx;
       const bool ok = cok && pval[i] && iy >= 0 && iy < H && ix >= 0 && ix < W;
       const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), W - 1);
-      uint4 v = *reinterpret_cast<const uint4*>(src + (pbase[i] + (int64_t)iyc * W + ixc) * sg_C);
-      if (!ok) v = uint4{0u, 0u, 0u, 0u};
+      const uint4 v = *reinterpret_cast<const uint4*>(src + (pbase[i] + (int64_t)iyc * W + ixc) * sg_C);
       if constexpr (S == 0) areg0[i] = v; else areg1[i] = v;
+      okm |= ok ? (1u << i) : 0u;
+    }
+    if constexpr (S == 0) okm0 = okm; else okm1 = okm;
+    if constexpr (GNP) {
+      const int sgn = ks == 0 ? p.seg_gn[0] : ks == 1 ? p.seg_gn[1] : ks == 2 ? p.seg_gn[2] : p.seg_gn[3];
+      const int cb = sgn >= 0 ? sgn + kc * KC + lchunk * VW : -1;
+      if constexpr (S == 0) gcb0 = cb; else gcb1 = cb;
     }
     const T* wp = reinterpret_cast<const T*>(p.w) + ((int64_t)kidx * p.CoutPad + n0 + lrow) * KC + lchunk * VW;
 #pragma unroll
@@ -170,7 +257,37 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
       const int row = lrow + 32 * i;
-      *reinterpret_cast<uint4*>(A + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = (S == 0 ? areg0[i] : areg1[i]);
+      uint4 v = (S == 0 ? areg0[i] : areg1[i]);
+      const unsigned okm = (S == 0 ? okm0 : okm1);
+      if constexpr (GNP) {
+        const int cb = (S == 0 ? gcb0 : gcb1);
+        if (cb >= 0) {             // wave-uniform per k-step (a property of the segment)
+          const float2* tab = s_gn + pbl[i] * p.gn_C + cb;
+          if constexpr (sizeof(T) == 2) {
+            bf16x8 e = *reinterpret_cast<bf16x8*>(&v);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+              const float2 ss = tab[q];
+              float y = (float)e[q] * ss.x + ss.y;
+              if (p.gn_silu) y = silu_f(y);
+              e[q] = (bf16_t)y;
+            }
+            v = *reinterpret_cast<uint4*>(&e);
+          } else {
+            f32x4 e = *reinterpret_cast<f32x4*>(&v);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float2 ss = tab[q];
+              float y = e[q] * ss.x + ss.y;
+              if (p.gn_silu) y = silu_precise(y);
+              e[q] = y;
+            }
+            v = *reinterpret_cast<uint4*>(&e);
+          }
+        }
+      }
+      if (!((okm >> i) & 1u)) v = uint4{0u, 0u, 0u, 0u};     // zero padding AFTER the activation
+      *reinterpret_cast<uint4*>(A + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4)) = v;
     }
 #pragma unroll
     for (int i = 0; i < WROWS; ++i) {
@@ -253,6 +370,37 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
   };
 
+  auto build_gn_table = [&]() __attribute__((always_inline)) {
+  if constexpr (GNP) {
+    float* s_mr = s_stat + CONV_MAX_NB * 64;                                  // [nb][32][2] mean, rstd
+    const int64_t mlast = min(M, m0 + BM) - 1;
+    const int nb = (int)(mlast / HW) - b0 + 1;
+    const int G = p.gn_G, C = p.gn_C;
+    for (int i = tid; i < nb * G; i += 256) {
+      const int bl = i / G, g = i - bl * G;
+      double a0 = 0.0, a1 = 0.0;
+      for (int sp = 0; sp < p.gn_nsplit; ++sp) {
+        const float* q = p.gn_sums + ((((int64_t)(b0 + bl)) * p.gn_nsplit + sp) * G + g) * 2;
+        a0 += (double)q[0];
+        a1 += (double)q[1];
+      }
+      const double mean = a0 * p.gn_inv_count;
+      double var = a1 * p.gn_inv_count - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mr[2 * i] = (float)mean;
+      s_mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int i = tid; i < nb * C; i += 256) {
+      const int bl = i / C, c = i - bl * C;
+      const int g = c / cpg;
+      const float sc = s_mr[2 * (bl * G + g) + 1] * p.gn_gamma[c];
+      s_gn[i] = float2{sc, p.gn_beta[c] - s_mr[2 * (bl * G + g)] * sc};
+    }
+  }
+  };
+
   // ---- main loop: loads run two k-steps ahead of the MFMAs ------------------------------
   //   iteration t:  issue loads of step t+2 -> regs[t&1] ; MFMAs on LDS buf[t&1] ;
   //                 regs[(t+1)&1] (issued one iteration ago) -> LDS buf[(t+1)&1] ; barrier
@@ -261,6 +409,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   if (nloc > 0) {
     load_regs(S0{}, kbeg);
     if (nloc > 1) load_regs(S1{}, kbeg + 1);
+    build_gn_table();            // its global reads overlap the first two k-steps' loads
+    __syncthreads();
     write_lds(S0{}, 0);
     __syncthreads();
     int t = 0;
@@ -295,78 +445,114 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
     return;
   }
-  TO* out = reinterpret_cast<TO*>(p.out);
-  const TO* res = reinterpret_cast<const TO*>(p.res);
+  const bool do_stat = p.stat_out != nullptr;
+  const int scpg = do_stat ? Cout / p.stat_G : 1;
+  // all m-tiles of this wave in one image (H*W a multiple of the wave tile): sum over them first
+  const bool one_img = (HW % WTM) == 0;
+  float a1[NT], a2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) a1[j] = a2[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
-    const int64_t m = m0 + wm * WTM + i * 16 + frow;
-    if (m >= M) continue;
-    const int64_t b = m / HW;
+    const int64_t mt0 = m0 + wm * WTM + i * 16;          // first pixel of this 16-pixel m-tile
+    const int64_t m = mt0 + frow;
+    const int64_t b = (m < M ? m : M - 1) / HW;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + wn * WTN + j * 16 + fk * 4;
-      if (n >= Cout) continue;
       float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-      if (p.bias) {
-        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-        v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+      const bool live = m < M && n < Cout;
+      if (live) conv_epilogue4<TO>(p, m, b, n, v);
+      if (do_stat) {
+        const float s1 = live ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+        const float s2 = live ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.f;
+        if (one_img) {
+          a1[j] += s1;
+          a2[j] += s2;
+        } else {
+          // the 16 pixels of an m-tile lie in one image (H*W % 16 == 0)
+          const float r1 = row16_sum(s1), r2 = row16_sum(s2);
+          if (frow == 0 && mt0 < M && n < Cout) {
+            const int bl = (int)(mt0 / HW) - b0;
+            atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2], r1);
+            atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2 + 1], r2);
+          }
+        }
       }
-      if (p.tbias) {
-        const f32x4 tv = *reinterpret_cast<const f32x4*>(p.tbias + b * p.tbias_stride + n);
-        v[0] += tv[0]; v[1] += tv[1]; v[2] += tv[2]; v[3] += tv[3];
+    }
+  }
+  if (do_stat && one_img) {
+    const int64_t mw = m0 + wm * WTM;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + fk * 4;
+      const float r1 = row16_sum(a1[j]), r2 = row16_sum(a2[j]);
+      if (frow == 0 && mw < M && n < Cout) {
+        const int bl = (int)(mw / HW) - b0;
+        atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2], r1);
+        atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2 + 1], r2);
       }
-      if (res) {
-        float r[4];
-        OutVec<TO>::load(res + m * Cout + n, r);
-        v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
-      }
-      v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale;
-      OutVec<TO>::store(out + m * Cout + n, v);
+    }
+  }
+  if (do_stat) {
+    __syncthreads();
+    const int64_t mlast = min(M, m0 + BM) - 1;
+    const int nb = (int)(mlast / HW) - b0 + 1;
+    const int g0 = n0 / scpg;
+    const int ng = min(p.stat_G - g0, (BN + scpg - 1) / scpg);
+    for (int i = tid; i < nb * ng * 2; i += 256) {
+      const int k = i & 1, g = g0 + (i >> 1) % ng, bl = (i >> 1) / ng;
+      // spread over stat_nsplit rows: hundreds of blocks adding into ONE row serialise at memory
+      atomicAdd(p.stat_out + (((int64_t)(b0 + bl) * p.stat_nsplit + blockIdx.x % p.stat_nsplit) * p.stat_G + g) * 2 + k,
+                s_stat[(bl * 32 + g) * 2 + k]);
     }
   }
 }
 
-// split-K reduction + epilogue: out = (sum_z slab[z] + bias + tbias + res) * scale
+// split-K reduction + epilogue: out = epilogue(sum_z slab[z]); one image per blockIdx.y so the
+// output statistics of a block belong to one (image, group) row.
 template <typename TO>
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParams p) {
+  __shared__ float s_stat[64];
   const int Cout = p.Cout;
   const int HW = p.H * p.W;
   const int64_t M = (int64_t)p.B * HW;
   const int nv = Cout / 4;
-  const int64_t total = M * nv;
-  TO* out = reinterpret_cast<TO*>(p.out);
-  const TO* res = reinterpret_cast<const TO*>(p.res);
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int n = (int)(i % nv) * 4;
-    const int64_t m = i / nv;
+  const int b = blockIdx.y;
+  const bool do_stat = p.stat_out != nullptr;
+  const int scpg = do_stat ? Cout / p.stat_G : 1;
+  if (do_stat) {
+    if (threadIdx.x < 64) s_stat[threadIdx.x] = 0.f;
+    __syncthreads();
+  }
+  const int total = HW * nv;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int n = (i % nv) * 4;
+    const int64_t m = (int64_t)b * HW + i / nv;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     for (int z = 0; z < p.ksplit; ++z) a += *reinterpret_cast<const f32x4*>(p.partial + ((int64_t)z * M + m) * Cout + n);
     float v[4] = {a[0], a[1], a[2], a[3]};
-    if (p.bias) {
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-      v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+    conv_epilogue4<TO>(p, m, b, n, v);
+    if (do_stat) {
+      const int g = n / scpg;
+      atomicAdd(&s_stat[g * 2], (v[0] + v[1]) + (v[2] + v[3]));
+      atomicAdd(&s_stat[g * 2 + 1], (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
     }
-    if (p.tbias) {
-      const f32x4 tv = *reinterpret_cast<const f32x4*>(p.tbias + (m / HW) * p.tbias_stride + n);
-      v[0] += tv[0]; v[1] += tv[1]; v[2] += tv[2]; v[3] += tv[3];
-    }
-    if (res) {
-      float r[4];
-      OutVec<TO>::load(res + m * Cout + n, r);
-      v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
-    }
-    v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale;
-    OutVec<TO>::store(out + m * Cout + n, v);
+  }
+  if (do_stat) {
+    __syncthreads();
+    if (threadIdx.x < p.stat_G * 2)
+      atomicAdd(p.stat_out + ((int64_t)b * p.stat_nsplit + blockIdx.x % p.stat_nsplit) * p.stat_G * 2 + threadIdx.x,
+                s_stat[threadIdx.x]);
   }
 }
 
-template <typename T, typename TO, int BM, int BN>
+template <typename T, typename TO, int BM, int BN, bool GNP>
 static int launch_conv(const ConvParams& p, hipStream_t st) {
-  constexpr int SMEM = 2 * (BM + BN) * 128;
+  constexpr int SMEM = 2 * (BM + BN) * 128 + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0) + CONV_MAX_NB * 64 * 4 * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, TO, BM, BN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, TO, BM, BN, GNP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) {
       fdbm_set_error("fdbm_conv_igemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -376,13 +562,13 @@ static int launch_conv(const ConvParams& p, hipStream_t st) {
   }
   const int64_t M = (int64_t)p.B * p.H * p.W;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((p.Cout + BN - 1) / BN), (unsigned)p.ksplit);
-  conv_igemm_kernel<T, TO, BM, BN><<<grid, 256, SMEM, st>>>(p);
+  conv_igemm_kernel<T, TO, BM, BN, GNP><<<grid, 256, SMEM, st>>>(p);
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm");
   if (p.ksplit > 1) {
-    const int64_t total = M * (p.Cout / 4);
-    int g = (int)((total + 255) / 256);
-    if (g > 2048) g = 2048;
-    conv_splitk_reduce_kernel<TO><<<g, 256, 0, st>>>(p);
+    const int total = p.H * p.W * (p.Cout / 4);
+    int g = (total + 255) / 256;
+    if (g > 256) g = 256;
+    conv_splitk_reduce_kernel<TO><<<dim3(g, p.B), 256, 0, st>>>(p);
     FDBM_LAUNCH_CHECK("fdbm_conv_igemm/reduce");
   }
   return 0;
@@ -390,10 +576,15 @@ static int launch_conv(const ConvParams& p, hipStream_t st) {
 
 template <typename T, typename TO>
 static int launch_conv_tile(const ConvParams& p, int bm, int bn, hipStream_t st) {
-  if (bm == 128 && bn == 128) return launch_conv<T, TO, 128, 128>(p, st);
-  if (bm == 128 && bn == 64) return launch_conv<T, TO, 128, 64>(p, st);
-  if (bm == 64 && bn == 128) return launch_conv<T, TO, 64, 128>(p, st);
-  return launch_conv<T, TO, 64, 64>(p, st);
+  if (p.gn_sums) {            // GN prologue: only the small-M configurations are built
+    if (bm == 128 && bn == 128) return launch_conv<T, TO, 128, 128, true>(p, st);
+    if (bn == 128) return launch_conv<T, TO, 64, 128, true>(p, st);
+    return launch_conv<T, TO, 64, 64, true>(p, st);
+  }
+  if (bm == 128 && bn == 128) return launch_conv<T, TO, 128, 128, false>(p, st);
+  if (bm == 128 && bn == 64) return launch_conv<T, TO, 128, 64, false>(p, st);
+  if (bm == 64 && bn == 128) return launch_conv<T, TO, 64, 128, false>(p, st);
+  return launch_conv<T, TO, 64, 64, false>(p, st);
 }
 
 extern "C" int fdbm_conv_kc(int dtype) { return dtype == FDBM_BF16 ? 64 : 32; }
@@ -457,6 +648,34 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   while (ks > 1 && (int64_t)ks * M * a->Cout * 4 > a->workspace_bytes) --ks;
   p.ksplit = ks;
   p.partial = reinterpret_cast<float*>(a->workspace);
+  const int HW = a->H * a->W;
+  for (int s = 0; s < FDBM_MAX_SEG; ++s) p.seg_gn[s] = -1;
+  if (a->gn_sums) {
+    FDBM_CHECK(a->gn_gamma && a->gn_beta && a->gn_G > 0 && a->gn_G <= 32 && a->gn_C > 0 && a->gn_C <= CONV_GN_MAXC &&
+               a->gn_C % a->gn_G == 0 && a->gn_nsplit >= 1 && a->gn_count > 0,
+               "fdbm_conv_igemm: bad GroupNorm prologue arguments (G=%d C=%d nsplit=%d)", a->gn_G, a->gn_C, a->gn_nsplit);
+    FDBM_CHECK(HW % 16 == 0 && (HW % bm == 0 || (bm % HW == 0 && bm / HW <= CONV_MAX_NB)),
+               "fdbm_conv_igemm: GroupNorm prologue needs H*W (%d) to tile the %d-pixel M tile", HW, bm);
+    int coff = 0;
+    for (int s = 0; s < a->nseg; ++s)
+      if (a->seg_gn_mask & (1u << s)) { p.seg_gn[s] = coff; coff += a->seg[s].cin; }
+    FDBM_CHECK(coff == a->gn_C, "fdbm_conv_igemm: GroupNorm channels %d != flagged segment channels %d", a->gn_C, coff);
+    p.gn_sums = a->gn_sums; p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta;
+    p.gn_nsplit = a->gn_nsplit; p.gn_G = a->gn_G; p.gn_C = a->gn_C; p.gn_silu = a->gn_silu;
+    p.gn_inv_count = 1.0 / (double)a->gn_count; p.gn_eps = a->gn_eps;
+  }
+  if (a->comb_pyr) {
+    FDBM_CHECK(a->comb_w && a->comb_b, "fdbm_conv_igemm: Combine epilogue needs comb_w and comb_b");
+    p.comb_pyr = a->comb_pyr; p.comb_w = a->comb_w; p.comb_b = a->comb_b;
+  }
+  if (a->stat_out) {
+    FDBM_CHECK(a->stat_G > 0 && a->stat_G <= 32 && a->Cout % a->stat_G == 0 && (a->Cout / a->stat_G) % 4 == 0,
+               "fdbm_conv_igemm: output statistics need Cout/G (%d/%d) to be a multiple of 4", a->Cout, a->stat_G);
+    FDBM_CHECK(HW % 16 == 0 && (HW % bm == 0 || (bm % HW == 0 && bm / HW <= CONV_MAX_NB)),
+               "fdbm_conv_igemm: output statistics need H*W (%d) to tile the %d-pixel M tile", HW, bm);
+    FDBM_CHECK(a->stat_nsplit >= 1, "fdbm_conv_igemm: stat_nsplit must be >= 1");
+    p.stat_out = a->stat_out; p.stat_G = a->stat_G; p.stat_nsplit = a->stat_nsplit;
+  }
   hipStream_t st = (hipStream_t)stream;
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_BF16) return launch_conv_tile<bf16_t, bf16_t>(p, bm, bn, st);
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_F32) return launch_conv_tile<bf16_t, float>(p, bm, bn, st);

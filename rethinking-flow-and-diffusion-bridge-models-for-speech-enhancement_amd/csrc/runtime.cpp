@@ -15,6 +15,13 @@ void fdbm_set_error(const char* fmt, ...) {
 extern "C" const char* fdbm_last_error(void) { return g_err; }
 extern "C" int fdbm_version(void) { return 1; }
 
+extern "C" int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream) {
+  FDBM_CHECK(ptr && bytes >= 0, "fdbm_memset_zero: bad arguments");
+  hipError_t e = hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream);
+  FDBM_CHECK(e == hipSuccess, "fdbm_memset_zero: %s", hipGetErrorString(e));
+  return 0;
+}
+
 #define P(i) ((void*)(intptr_t)o.iarg[i])
 #define CP(i) ((const void*)(intptr_t)o.iarg[i])
 #define FP(i) ((float*)(intptr_t)o.iarg[i])
@@ -70,6 +77,9 @@ extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* stream) {
       case FDBM_OP_UPDATE:
         rc = fdbm_bridge_update(P(0), CP(1), CP(2), CP(3), CFP(4), CFP(5), CFP(6), I(7), o.iarg[8],
                                 stream);
+        break;
+      case FDBM_OP_MEMSET:
+        rc = fdbm_memset_zero(P(0), o.iarg[1], stream);
         break;
       default:
         fdbm_set_error("fdbm_run_program: unknown opcode %d at op %d", o.opcode, k);

@@ -33,7 +33,13 @@ class ConvArgs(ctypes.Structure):
                 ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
                 ("Cout", ctypes.c_int32), ("CoutPad", ctypes.c_int32),
                 ("dt_in", ctypes.c_int32), ("dt_out", ctypes.c_int32),
-                ("workspace", c_void_p), ("workspace_bytes", c_i64)]
+                ("workspace", c_void_p), ("workspace_bytes", c_i64),
+                ("gn_sums", c_void_p), ("gn_gamma", c_void_p), ("gn_beta", c_void_p),
+                ("gn_nsplit", ctypes.c_int32), ("gn_G", ctypes.c_int32), ("gn_C", ctypes.c_int32),
+                ("gn_silu", ctypes.c_int32), ("gn_count", c_i64), ("gn_eps", c_float),
+                ("seg_gn_mask", ctypes.c_uint32),
+                ("comb_pyr", c_void_p), ("comb_w", c_void_p), ("comb_b", c_void_p),
+                ("stat_out", c_void_p), ("stat_G", ctypes.c_int32), ("stat_nsplit", ctypes.c_int32)]
 
 
 class Op(ctypes.Structure):
@@ -42,7 +48,7 @@ class Op(ctypes.Structure):
 
 
 OP_CONV, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_RESAMPLE, OP_COMBINE, OP_ATTENTION, \
-    OP_STEM, OP_PACK, OP_UNPACK, OP_TEMB, OP_DENSE, OP_UPDATE = range(1, 14)
+    OP_STEM, OP_PACK, OP_UNPACK, OP_TEMB, OP_DENSE, OP_UPDATE, OP_MEMSET = range(1, 15)
 
 # name -> (argtypes without the trailing stream)
 _SIGS = {
@@ -66,6 +72,7 @@ _SIGS = {
     "fdbm_istft": [c_void_p] * 4 + [c_int] * 7 + [c_float, c_float],
     "fdbm_spec_transform": [c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_int],
     "fdbm_pad_spec": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int],
+    "fdbm_memset_zero": [c_void_p, c_i64],
     "fdbm_run_program": [ctypes.POINTER(Op), c_int],
 }
 EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan"])

@@ -108,10 +108,11 @@ def pack_conv_weight(segments, kc, dtype, device):
 
 class Act:
     """An NHWC activation living in a pooled buffer."""
-    __slots__ = ("t", "B", "H", "W", "C", "dtype")
+    __slots__ = ("t", "B", "H", "W", "C", "dtype", "stats")
 
     def __init__(self, t, B, H, W, C, dtype):
         self.t, self.B, self.H, self.W, self.C, self.dtype = t, B, H, W, C, dtype
+        self.stats = {}      # G -> (sums buffer, nsplit, count) produced by the conv that wrote it
 
     @property
     def ptr(self):
@@ -166,6 +167,12 @@ class Program:
         self.keep = []         # tensors that must outlive the program
         self.keep_conv = []    # ConvArgs structs, one per conv op, in op order
         self.splitk_ws = None
+        self.fused = net.fused
+        # (sum, sumsq) slots [slot][B][32][2] that conv epilogues accumulate into with atomics;
+        # zeroed by ONE memset at the head of every forward
+        self.arena = torch.zeros(256 * 1024 * B, dtype=torch.float32, device=net.device)   # 1 MiB per sample
+        self.arena_used = 0        # floats
+        self.n_slots = 0
         self.macs = 0
         dev = self.dev
         self.x_in = torch.zeros(B, 1, F, T, dtype=torch.complex64, device=dev)
@@ -192,9 +199,20 @@ class Program:
     def emit(self, opcode, iargs, fargs=()):
         self.ops.append((opcode, [int(v) for v in iargs], [float(v) for v in fargs]))
 
+    def stats_for(self, srcs, G):
+        """(sums buffer or slot pointer, nsplit, count, owned) of GroupNorm(G) over cat(srcs):
+        the producer's fused statistics when a single source carries them, else a stats pass."""
+        if len(srcs) == 1 and G in srcs[0].stats:
+            return srcs[0].stats[G], False
+        return self.gn_stats(srcs, G), True
+
+    def release_stats(self, st, owned):
+        if owned:
+            self.pool.put(st[0])
+
     def gn_stats(self, srcs, G):
         """srcs: list of 1 or 2 Acts (virtual concat) -> (partial sums buffer, nsplit, count);
-        the consumers (gn_apply / resample) finish the reduction themselves."""
+        the consumers (gn_apply / resample / conv prologue) finish the reduction themselves."""
         a0 = srcs[0]
         a1 = srcs[1] if len(srcs) > 1 else None
         HW = a0.H * a0.W
@@ -211,14 +229,35 @@ class Program:
         C = a0.C + (a1.C if a1 else 0)
         out = self.new_act(a0.H, a0.W, C)
         partial, nsplit, count = st
+        pptr = partial if isinstance(partial, int) else partial.data_ptr()
         self.emit(hip.OP_GN_APPLY, [out.ptr, a0.ptr, a0.C, a1.ptr if a1 else 0, a1.C if a1 else 0,
-                                    partial.data_ptr(), nsplit, count, gamma.data_ptr(), beta.data_ptr(),
+                                    pptr, nsplit, count, gamma.data_ptr(), beta.data_ptr(),
                                     self.B, a0.H * a0.W, G, 1 if silu else 0, self.dtc], [1e-6])
         return out
 
+    def new_slot(self, nsplit, G):
+        n = self.B * nsplit * G * 2
+        assert self.arena_used + n <= self.arena.numel()
+        ptr = self.arena.data_ptr() + self.arena_used * 4
+        self.arena_used += (n + 63) // 64 * 64
+        self.n_slots += 1
+        return ptr
+
+    def tile_ok(self, HW, M, cout, nk):
+        """Can a conv of this shape carry a GN prologue / output statistics?  Its M tile must
+        lie in one image or cover at most 4 whole images (csrc/conv.hip CONV_MAX_NB)."""
+        bm, _, _ = hip.conv_plan(M, cout, nk)
+        return HW % 16 == 0 and (HW % bm == 0 or (bm % HW == 0 and bm // HW <= 4))
+
+    def nk_of(self, segs):
+        kc = hip.conv_kc(self.dtc)
+        return sum(taps * ((cin + kc - 1) // kc) for (_, _, cin, taps) in segs)
+
     def conv(self, segs, wpack, cout_pad, cout, bias, out_dtype=None, tbias=None, tb_stride=0,
-             res=None, scale=1.0):
-        """segs: list of (Act, coff, cin, taps)."""
+             res=None, scale=1.0, gn=None, comb=None, want_stats=0):
+        """segs: list of (Act, coff, cin, taps).
+        gn: (stats, gamma, beta, G, C, silu, n_flagged_segments) -> fused GroupNorm prologue.
+        comb: (pyr Act, w, b) -> fused Combine.  want_stats: G of the consuming GroupNorm (0: none)."""
         a0 = segs[0][0]
         out = self.new_act(a0.H, a0.W, cout, out_dtype or self.dt)
         ca = hip.ConvArgs()
@@ -237,8 +276,26 @@ class Program:
         ca.B, ca.H, ca.W, ca.Cout, ca.CoutPad = self.B, a0.H, a0.W, cout, cout_pad
         ca.dt_in = hip.dt_code(a0.dtype)
         ca.dt_out = hip.dt_code(out.dtype)
+        if gn is not None:
+            (gbuf, gnsplit, gcount), gamma, beta, G, C, silu, nflag = gn
+            ca.gn_sums = gbuf if isinstance(gbuf, int) else gbuf.data_ptr()
+            ca.gn_gamma, ca.gn_beta = gamma.data_ptr(), beta.data_ptr()
+            ca.gn_nsplit, ca.gn_G, ca.gn_C, ca.gn_silu = gnsplit, G, C, 1 if silu else 0
+            ca.gn_count, ca.gn_eps = gcount, 1e-6
+            ca.seg_gn_mask = (1 << nflag) - 1
+        if comb is not None:
+            cp, cw, cb = comb
+            ca.comb_pyr, ca.comb_w, ca.comb_b = cp.ptr, cw.data_ptr(), cb.data_ptr()
         kc = hip.conv_kc(ca.dt_in)
         nk = sum(taps * ((cin + kc - 1) // kc) for (_, _, cin, taps) in segs)
+        HW = a0.H * a0.W
+        if want_stats and self.fused and (cout // want_stats) % 4 == 0 and cout % want_stats == 0 \
+                and self.tile_ok(HW, a0.M, cout, nk):
+            bm, _, _ = hip.conv_plan(a0.M, cout, nk)
+            nsp = max(1, min(16, (HW // bm) // 8))      # rows the blocks' atomics are spread over
+            slot = self.new_slot(nsp, want_stats)
+            ca.stat_out, ca.stat_G, ca.stat_nsplit = slot, want_stats, nsp
+            out.stats[want_stats] = (slot, nsp, HW * (cout // want_stats))
         _, _, ks = hip.conv_plan(a0.M, cout, nk)
         if ks > 1:                      # split-K slabs: one shared scratch, ops run in order
             need = ks * a0.M * cout * 4
@@ -255,47 +312,82 @@ class Program:
         plain = self.new_act(OH, OW, a.C, a.dtype) if want_plain else None
         act = self.new_act(OH, OW, a.C, a.dtype) if st is not None else None
         partial, nsplit, count = st if st is not None else (None, 0, 0)
+        pptr = 0 if partial is None else (partial if isinstance(partial, int) else partial.data_ptr())
         self.emit(hip.OP_RESAMPLE, [plain.ptr if plain else 0, act.ptr if act else 0, a.ptr,
-                                    partial.data_ptr() if partial is not None else 0, nsplit, count,
+                                    pptr, nsplit, count,
                                     gamma.data_ptr() if gamma is not None else 0,
                                     beta.data_ptr() if beta is not None else 0,
                                     self.B, a.H, a.W, a.C, G, 1 if up else 0, hip.dt_code(a.dtype)], [1e-6])
         return plain, act
 
     # ---- blocks ------------------------------------------------------------------------
-    def resblock(self, mod, srcs):
-        """srcs: [h] or [h, skip]; returns the block output Act.  Does not free srcs."""
+    FUSE_PROLOGUE_MAX_HW = 256       # tap-outer conv redoes the GN per tap: only where latency-bound
+
+    def resblock(self, mod, srcs, comb=None):
+        """srcs: [h] or [h, skip]; comb: (pyr Act, w, b) folds Combine into the last conv.
+        Returns the block output Act.  Does not free srcs."""
         W = self.net.w[mod.idx]
         in_ch, out_ch = mod.in_ch, mod.out_ch
         G0, G1 = gn_groups(in_ch), gn_groups(out_ch)
-        mr0 = self.gn_stats(srcs, G0)
-        xr = None
+        Gout = gn_groups(out_ch)
+        H, Wd = srcs[0].H, srcs[0].W
+        st0, own0 = self.stats_for(srcs, G0)
+        tb = self.net.dense_out_ptr(self, mod.idx)
+        xr = a0 = None
         if mod.up or mod.down:
             assert len(srcs) == 1
-            xr, a0 = self.resample(srcs[0], mod.up, mr0, W["gn0_w"], W["gn0_b"], G0)
+            xr, a0 = self.resample(srcs[0], mod.up, st0, W["gn0_w"], W["gn0_b"], G0)
             short_srcs = [xr]
+            segs0 = [(a0, 0, in_ch, 9)]
+            gn0 = None
         else:
-            a0 = self.gn_apply(srcs, mr0, W["gn0_w"], W["gn0_b"], G0, True)
             short_srcs = srcs
-        self.pool.put(mr0[0])
-        tb = self.net.dense_out_ptr(self, mod.idx)
-        h1 = self.conv([(a0, 0, in_ch, 9)], W["conv0"], W["conv0_pad"], out_ch, W["conv0_b"],
-                       tbias=tb, tb_stride=self.net.dense_rows)
-        self.free_act(a0)
-        mr1 = self.gn_stats([h1], G1)
-        a1 = self.gn_apply([h1], mr1, W["gn1_w"], W["gn1_b"], G1, True)
-        self.pool.put(mr1[0])
-        self.free_act(h1)
-        segs = [(a1, 0, out_ch, 9)]
+            segs0 = [(s, 0, s.C, 9) for s in srcs]
+            fuse = (self.fused and H * Wd <= self.FUSE_PROLOGUE_MAX_HW and in_ch <= 512
+                    and self.tile_ok(H * Wd, srcs[0].M, out_ch, self.nk_of(segs0)))
+            if fuse:
+                gn0 = (st0, W["gn0_w"], W["gn0_b"], G0, in_ch, True, len(srcs))
+            else:
+                gn0 = None
+                a0 = self.gn_apply(srcs, st0, W["gn0_w"], W["gn0_b"], G0, True)
+                off, segs0 = 0, []
+                for s_ in srcs:          # same per-source weight packing, one activated tensor
+                    segs0.append((a0, off, s_.C, 9))
+                    off += s_.C
+        h1 = self.conv(segs0, W["conv0"], W["conv0_pad"], out_ch, W["conv0_b"], tbias=tb,
+                       tb_stride=self.net.dense_rows, gn=gn0, want_stats=G1)
+        self.release_stats(st0, own0)
+        if a0 is not None:
+            self.free_act(a0)
+        st1, own1 = self.stats_for([h1], G1)
+        segs1 = [(h1, 0, out_ch, 9)]
+        fuse1 = (self.fused and h1.H * h1.W <= self.FUSE_PROLOGUE_MAX_HW
+                 and self.tile_ok(h1.H * h1.W, h1.M, out_ch, self.nk_of(segs1) + len(short_srcs) * 8))
+        a1 = None
+        if fuse1:
+            gn1 = (st1, W["gn1_w"], W["gn1_b"], G1, out_ch, True, 1)
+        else:
+            gn1 = None
+            a1 = self.gn_apply([h1], st1, W["gn1_w"], W["gn1_b"], G1, True)
+            segs1 = [(a1, 0, out_ch, 9)]
         res = None
         if W["has_conv2"]:
-            for s in short_srcs:
-                segs.append((s, 0, s.C, 1))
+            for s_ in short_srcs:
+                segs1.append((s_, 0, s_.C, 1))
         else:
             assert len(short_srcs) == 1 and short_srcs[0].C == out_ch
             res = short_srcs[0]
-        out = self.conv(segs, W["conv1"], W["conv1_pad"], out_ch, W["conv1_b"], res=res, scale=_INV_SQRT2)
-        self.free_act(a1)
+        if fuse1 and not self.tile_ok(h1.H * h1.W, h1.M, out_ch, self.nk_of(segs1)):
+            # (the exact k-step count decides the tile; fall back rather than violate the contract)
+            gn1 = None
+            a1 = self.gn_apply([h1], st1, W["gn1_w"], W["gn1_b"], G1, True)
+            segs1[0] = (a1, 0, out_ch, 9)
+        out = self.conv(segs1, W["conv1"], W["conv1_pad"], out_ch, W["conv1_b"], res=res, scale=_INV_SQRT2,
+                        gn=gn1, comb=comb, want_stats=Gout)
+        self.release_stats(st1, own1)
+        if a1 is not None:
+            self.free_act(a1)
+        self.free_act(h1)
         if xr is not None:
             self.free_act(xr)
         return out
@@ -304,17 +396,26 @@ class Program:
         W = self.net.w[mod.idx]
         C = mod.in_ch
         G = gn_groups(C)
-        mr = self.gn_stats([x], G)
-        a = self.gn_apply([x], mr, W["gn_w"], W["gn_b"], G, False)
-        self.pool.put(mr[0])
-        qkv = self.conv([(a, 0, C, 1)], W["qkv"], W["qkv_pad"], 3 * C, W["qkv_b"])
-        self.free_act(a)
+        st, own = self.stats_for([x], G)
+        segs = [(x, 0, C, 1)]
+        a = None
+        if self.fused and self.tile_ok(x.H * x.W, x.M, 3 * C, self.nk_of(segs)):
+            gn = (st, W["gn_w"], W["gn_b"], G, C, False, 1)      # 1 tap: the prologue costs nothing extra
+        else:
+            gn = None
+            a = self.gn_apply([x], st, W["gn_w"], W["gn_b"], G, False)
+            segs = [(a, 0, C, 1)]
+        qkv = self.conv(segs, W["qkv"], W["qkv_pad"], 3 * C, W["qkv_b"], gn=gn)
+        self.release_stats(st, own)
+        if a is not None:
+            self.free_act(a)
         N = x.H * x.W
         att = self.new_act(x.H, x.W, C)
         self.emit(hip.OP_ATTENTION, [att.ptr, qkv.ptr, self.B, N, C, self.dtc])
         self.macs += 2 * N * N * C
         self.free_act(qkv)
-        out = self.conv([(att, 0, C, 1)], W["proj"], W["proj_pad"], C, W["proj_b"], res=x, scale=_INV_SQRT2)
+        out = self.conv([(att, 0, C, 1)], W["proj"], W["proj_pad"], C, W["proj_b"], res=x, scale=_INV_SQRT2,
+                        want_stats=G)
         self.free_act(att)
         return out
 
@@ -331,6 +432,9 @@ class Program:
             m = mods[mi[0]]
             mi[0] += 1
             return m
+
+        self.op_memset = len(self.ops)
+        self.emit(hip.OP_MEMSET, [self.arena.data_ptr(), 0])      # byte count patched in _finalize
 
         # time embedding + all Dense_0 rows
         self.temb_act = self.new_f32(B * 4 * nf)
@@ -365,15 +469,14 @@ class Program:
                     h = h2
                 hs.append(h)
             if lvl != nres - 1:
-                hd = self.resblock(nxt(), [hs[-1]])
-                comb = nxt()
+                down_mod, comb = nxt(), nxt()
                 pyr_down, _ = self.resample(pyr_in, False)
                 if pyr_in is not inp:
                     self.free_act(pyr_in)
                 pyr_in = pyr_down
                 cw = net.w[comb.idx]
-                self.emit(hip.OP_COMBINE, [hd.ptr, hd.ptr, pyr_in.ptr, cw["w"].data_ptr(), cw["b"].data_ptr(),
-                                           hd.M, hd.C, self.dtc])
+                # Combine('sum') rides in the epilogue of the down block's last conv
+                hd = self.resblock(down_mod, [hs[-1]], comb=(pyr_in, cw["w"], cw["b"]))
                 self.macs += hd.H * hd.W * IN_CH * hd.C
                 hs.append(hd)
         if pyr_in is not inp:
@@ -402,16 +505,24 @@ class Program:
             gnm, head = nxt(), nxt()
             G = gn_groups(h.C)
             gw, hw = net.w[gnm.idx], net.w[head.idx]
-            mr = self.gn_stats([h], G)
-            a = self.gn_apply([h], mr, gw["w"], gw["b"], G, True)
-            self.pool.put(mr[0])
+            st, own = self.stats_for([h], G)
             up_pyr = None
             if pyramid is not None:
                 up_pyr, _ = self.resample(pyramid, True)
                 self.free_act(pyramid)
-            pyramid = self.conv([(a, 0, h.C, 9)], hw["w"], hw["pad"], IN_CH, hw["b"],
-                                out_dtype=torch.float32, res=up_pyr, scale=1.0)
-            self.free_act(a)
+            segs = [(h, 0, h.C, 9)]
+            a = None
+            if self.fused and h.H * h.W <= self.FUSE_PROLOGUE_MAX_HW and self.tile_ok(h.H * h.W, h.M, IN_CH, self.nk_of(segs)):
+                gn = (st, gw["w"], gw["b"], G, h.C, True, 1)
+            else:
+                gn = None
+                a = self.gn_apply([h], st, gw["w"], gw["b"], G, True)
+                segs = [(a, 0, h.C, 9)]
+            pyramid = self.conv(segs, hw["w"], hw["pad"], IN_CH, hw["b"],
+                                out_dtype=torch.float32, res=up_pyr, scale=1.0, gn=gn)
+            self.release_stats(st, own)
+            if a is not None:
+                self.free_act(a)
             if up_pyr is not None:
                 self.free_act(up_pyr)
             if lvl != 0:
@@ -427,6 +538,7 @@ class Program:
         self.macs_per_sample = self.macs       # self.macs was accumulated per sample (H*W, not B*H*W)
 
     def _finalize(self):
+        self.ops[self.op_memset][1][1] = max(64, self.arena_used * 4)
         n = len(self.ops)
         arr = (hip.Op * n)()
         for i, (opc, ia, fa) in enumerate(self.ops):

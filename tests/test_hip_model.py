@@ -21,11 +21,11 @@ def T(a):
 _CACHE = {}
 
 
-def net(name, dtype=torch.float32):
-    key = (name, dtype)
+def net(name, dtype=torch.float32, fused=None):
+    key = (name, dtype, fused)
     if key not in _CACHE:
         hp = MINI64 if name == "mini64" else VARIANTS[name]
-        _CACHE[key] = HipNCSNpp(dtype=dtype, device=DEV, **hp)
+        _CACHE[key] = HipNCSNpp(dtype=dtype, device=DEV, fused=fused, **hp)
     return _CACHE[key]
 
 
@@ -39,6 +39,21 @@ def test_backbone_fp32_vs_reference(golden, name, fix):
     scale = ref.abs().max().item()
     assert err < 5e-5 * max(scale, 1.0), (err, scale)      # fp32 MFMA vs oneDNN summation order
     assert torch.all(out[:, :, 256] == 0)                  # Nyquist row re-appended as zeros
+
+
+@pytest.mark.parametrize("name,fix", [("mini64", "backbone_mini64"), ("ncsnpp_v2_5M", "backbone_v2_5M")])
+def test_backbone_fp32_fused_mode(golden, name, fix):
+    """The fused program (GroupNorm statistics from conv epilogues via fp32 atomics, GroupNorm+SiLU
+    inside the consuming conv, Combine in the epilogue) in f32 storage: same function, looser
+    tolerance because the statistics are summed in run-to-run order in fp32."""
+    g = golden(fix)
+    m = net(name, torch.float32, fused=True)
+    out = m(T(g["x"]).to(DEV), T(g["y"]).to(DEV), T(g["t"]).to(DEV)).cpu()
+    ref = T(g["out"])
+    err = (out - ref).abs().max().item()
+    assert err < 2e-4 * max(ref.abs().max().item(), 1.0), err
+    prog = m.program(*[int(v) for v in (g["x"].shape[0], g["x"].shape[2], g["x"].shape[3])])
+    assert prog.n_slots > 0
 
 
 @pytest.mark.parametrize("name,fix", [("mini64", "backbone_mini64"), ("ncsnpp_v2_5M", "backbone_v2_5M")])

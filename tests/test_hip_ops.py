@@ -179,7 +179,8 @@ def test_resample2x(dtype, tol, up):
         assert (nchw(o) - fn(p)).abs().max() < 1e-6
 
 
-def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=None, scale=1.0, splitk=False):
+def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=None, scale=1.0, splitk=False,
+             gn=None, comb=None, stat_G=0):
     """segs_nchw: list of (x NCHW cpu tensor, taps); weights: list of W [Cout, cin, k, k] per seg."""
     out_dtype = out_dtype or dtype
     kc = hip.conv_kc(hip.dt_code(dtype))
@@ -209,8 +210,31 @@ def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=No
     if splitk:
         ws = torch.empty(8 << 20, dtype=torch.uint8, device=DEV)
         ca.workspace, ca.workspace_bytes = ws.data_ptr(), ws.numel()
+    if gn is not None:
+        G, gamma, beta, silu, nseg_gn = gn
+        xc = torch.cat([k_.float().cpu() for k_ in keep[:nseg_gn]], 3)          # NHWC, what the device sees
+        Cg = xc.shape[3]
+        xg = xc.reshape(B, H * W, G, Cg // G)
+        sums = torch.stack([xg.sum((1, 3)), (xg * xg).sum((1, 3))], -1).to(DEV).contiguous()   # [B][G][2]
+        gd, bd2 = gamma.to(DEV), beta.to(DEV)
+        keep += [sums, gd, bd2]
+        ca.gn_sums, ca.gn_gamma, ca.gn_beta = sums.data_ptr(), gd.data_ptr(), bd2.data_ptr()
+        ca.gn_nsplit, ca.gn_G, ca.gn_C, ca.gn_silu = 1, G, Cg, int(silu)
+        ca.gn_count, ca.gn_eps = H * W * (Cg // G), 1e-6
+        ca.seg_gn_mask = (1 << nseg_gn) - 1
+    if comb is not None:
+        cp, cw, cb = comb
+        cpd, cwd, cbd = nhwc(cp), cw.to(DEV).contiguous(), cb.to(DEV)
+        keep += [cpd, cwd, cbd]
+        ca.comb_pyr, ca.comb_w, ca.comb_b = cpd.data_ptr(), cwd.data_ptr(), cbd.data_ptr()
+    st = None
+    if stat_G:
+        st = torch.zeros(B, 3, stat_G, 2, device=DEV)          # 3 atomic rows per image
+        ca.stat_out, ca.stat_G, ca.stat_nsplit = st.data_ptr(), stat_G, 3
     hip.call("fdbm_conv_igemm", ca)
     torch.cuda.synchronize()
+    if stat_G:
+        return nchw(out), keep, st.cpu().sum(1)
     return nchw(out), keep, rd
 
 
@@ -269,6 +293,59 @@ def test_conv_igemm(case, dtype, splitk):
     err = (out - ref).abs().max().item()
     tol = 2e-5 if dtype == torch.float32 else (2e-2 if out_dtype == torch.bfloat16 else 2e-3)
     assert err < tol, (name, err)
+
+
+FUSED_CASES = [
+    # name, B, H, W, cins, cout, G_in, G_out, shortcut, comb
+    ("blk_16x16", 2, 16, 16, [256], 256, 32, 32, False, False),
+    ("blk_4x4_b3", 3, 4, 4, [256], 256, 32, 32, False, False),
+    ("cat_8x8", 2, 8, 8, [256, 128], 128, 32, 32, True, False),
+    ("down_comb_32", 1, 32, 32, [128], 128, 32, 32, False, True),
+    ("big_m_stats", 1, 64, 64, [64], 128, 16, 32, False, False),
+]
+
+
+@pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
+def test_conv_fused_gn_combine_stats(case, dtype, splitk):
+    """conv3x3(silu(GroupNorm(cat(xs)))) [+ 1x1 shortcut of the raw input] [+ Combine] in one
+    launch, plus the (sum, sumsq) of the stored output for the next GroupNorm."""
+    name, B, H, W, cins, cout, G_in, G_out, shortcut, comb = case
+    xs = [rnd(B, c, H, W, seed=10 + i) * (1.5 if i == 0 else 0.7) + 0.2 * i for i, c in enumerate(cins)]
+    q = lambda t: t.to(dtype).float()
+    Cg = sum(cins)
+    gamma, beta = rnd(Cg, seed=3) * 0.1 + 1, rnd(Cg, seed=4) * 0.1
+    w = rnd(cout, Cg, 3, 3, seed=20) / math.sqrt(Cg * 9)
+    bias = rnd(cout, seed=30) * 0.1
+    xcat = torch.cat([q(x) for x in xs], 1)
+    act = F.silu(F.group_norm(xcat, G_in, gamma, beta, eps=1e-6))
+    if dtype == torch.bfloat16:
+        act = act.to(dtype).float()                       # the kernel stages the activation in bf16
+    ref = F.conv2d(act, q(w), bias, padding=1)
+    segs = [(x, 9) for x in xs]
+    off = 0
+    weights = []
+    for c in cins:
+        weights.append(w[:, off:off + c]); off += c
+    if shortcut:
+        sw = rnd(cout, Cg, 1, 1, seed=50) / math.sqrt(Cg)
+        ref = ref + F.conv2d(xcat, q(sw))
+        off = 0
+        for x, c in zip(xs, cins):
+            segs.append((x, 1)); weights.append(sw[:, off:off + c]); off += c
+    kw = dict(gn=(G_in, gamma, beta, True, len(cins)), stat_G=G_out, scale=1 / math.sqrt(2.0))
+    ref = ref / math.sqrt(2.0)
+    if comb:
+        cp, cw, cb = rnd(B, 4, H, W, seed=60), rnd(cout, 4, seed=61), rnd(cout, seed=62)
+        ref = ref + F.conv2d(cp, cw[:, :, None, None], cb)
+        kw["comb"] = (cp, cw, cb)
+    out, _, st = run_conv(segs, weights, bias, dtype, splitk=splitk, **kw)
+    tol = 3e-5 if dtype == torch.float32 else 3e-2
+    assert close(out, ref, tol), (name, float((out - ref).abs().max()))
+    og = out.reshape(B, G_out, -1)                         # stats of what was stored
+    ref_st = torch.stack([og.sum(-1), (og * og).sum(-1)], -1)
+    assert ((st - ref_st).abs() <= 1e-4 * (1 + ref_st.abs()) * (10 if dtype == torch.bfloat16 else 1)).all(), name
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])

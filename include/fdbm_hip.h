@@ -188,6 +188,10 @@ int fdbm_conv_kc(int dtype);
 /* tile / split-K plan the launcher will use for M pixels, Cout channels, nk k-steps
  * (the caller sizes `workspace` as ksplit * M * Cout * 4 bytes when ksplit > 1) */
 int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int* ksplit);
+/* full plan: kind 1 = halo-patch 3x3 kernel (tile th x 16 pixels, always inside one image),
+ * kind 0 = tap-outer implicit GEMM with the (bm, bn, ksplit) of fdbm_conv_plan */
+int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int first_taps, int* kind, int* th,
+                      int* bm, int* bn, int* ksplit);
 
 /* Combine('sum'): out = conv1x1(4->C)(pyr) + h (layerspp.py:52-57; ncsnpp_v2.py:302-305).
  * pyr f32 [M][4], w f32 [C][4], bias f32 [C], h/out dtype [M][C]; out may alias h. */

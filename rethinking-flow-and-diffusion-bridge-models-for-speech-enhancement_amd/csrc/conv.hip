@@ -19,125 +19,9 @@
 // to the other LDS buffer after the MFMAs of the step before them; one barrier per k-step.
 // Small-M layers (the 4x4 ... 32x32 levels at batch 1) split the k-steps over grid.z and a
 // second kernel sums the fp32 slabs and applies the epilogue (weights are streamed once).
-#include <type_traits>
+#include <stdlib.h>
 
-#include "common.h"
-
-template <typename T> struct Mfma;
-template <> struct Mfma<bf16_t> {
-  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& acc) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
-                                                  *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
-  }
-};
-
-template <typename TO> struct OutVec;
-template <> struct OutVec<float> {
-  __device__ static __forceinline__ void load(const float* p, float* v) {
-    f32x4 t = *reinterpret_cast<const f32x4*>(p);
-    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
-  }
-  __device__ static __forceinline__ void store(float* p, const float* v) {
-    f32x4 t = {v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(p) = t;
-  }
-};
-template <> struct OutVec<bf16_t> {
-  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
-    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
-    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
-  }
-  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
-    bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-    *reinterpret_cast<bf16x4*>(p) = t;
-  }
-};
-
-struct ConvParams {
-  fdbm_conv_seg seg[FDBM_MAX_SEG];
-  int nseg;
-  const void* w;
-  const float* bias;
-  const float* tbias;
-  int tbias_stride;
-  const void* res;
-  float scale;
-  void* out;
-  int B, H, W, Cout, CoutPad;
-  int nk;
-  int ksplit;       // grid.z: k-steps are split over this many workgroups
-  float* partial;   // fp32 slabs [ksplit][M][Cout] when ksplit > 1
-  // GroupNorm(+SiLU) applied to the A operand while it is staged (segments with seg_gn >= 0;
-  // seg_gn = channel offset of the segment inside the normalised, virtually concatenated input)
-  const float* gn_sums;     // [B][gn_nsplit][gn_G][2] (sum, sumsq) or NULL
-  const float* gn_gamma;
-  const float* gn_beta;
-  int gn_nsplit, gn_G, gn_C, gn_silu;
-  double gn_inv_count;
-  float gn_eps;
-  int seg_gn[FDBM_MAX_SEG];
-  // Combine('sum') folded into the epilogue: out += comb_b[n] + comb_w[n][0..3] . pyr[m][0..3]
-  const float* comb_pyr;
-  const float* comb_w;
-  const float* comb_b;
-  // (sum, sumsq) of the stored output per (image, group of Cout/stat_G channels), accumulated
-  // with atomics into stat_out[B][stat_G][2] for the GroupNorm that consumes this tensor
-  float* stat_out;
-  int stat_G;
-  int stat_nsplit;   // stat_out is [B][stat_nsplit][stat_G][2]; a block adds into split blockIdx.x % nsplit
-};
-
-// sum over the 16 lanes of a DPP row (= the 16 pixels of an MFMA m-tile), every lane gets it:
-// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - four VALU adds.
-__device__ __forceinline__ float row16_sum(float v) {
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
-  return v;
-}
-
-#define CONV_MAX_NB 4          // images one M tile may touch when a GN prologue / stats are on
-#define CONV_GN_MAXC 512
-
-// final value of 4 consecutive output channels of pixel m: bias, time-embedding bias, residual,
-// scale, Combine; stores and returns the stored (rounded) values in v.
-template <typename TO>
-__device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int64_t m, int64_t b, int n, float* v) {
-  const int Cout = p.Cout;
-  if (p.bias) {
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-    v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
-  }
-  if (p.tbias) {
-    const f32x4 tv = *reinterpret_cast<const f32x4*>(p.tbias + b * p.tbias_stride + n);
-    v[0] += tv[0]; v[1] += tv[1]; v[2] += tv[2]; v[3] += tv[3];
-  }
-  if (p.res) {
-    float r[4];
-    OutVec<TO>::load(reinterpret_cast<const TO*>(p.res) + m * Cout + n, r);
-    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
-  }
-  v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale;
-  if (p.comb_pyr) {
-    const f32x4 q = *reinterpret_cast<const f32x4*>(p.comb_pyr + m * 4);
-    const f32x4 cb = *reinterpret_cast<const f32x4*>(p.comb_b + n);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const f32x4 w = *reinterpret_cast<const f32x4*>(p.comb_w + (int64_t)(n + r) * 4);
-      v[r] += cb[r] + (((w[0] * q[0] + w[1] * q[1]) + w[2] * q[2]) + w[3] * q[3]);
-    }
-  }
-  OutVec<TO>::store(reinterpret_cast<TO*>(p.out) + m * Cout + n, v);
-  if constexpr (sizeof(TO) == 2) {     // statistics are those of the STORED tensor
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (float)(bf16_t)v[r];
-  }
-}
-
-// p.seg[ks] with a run-time ks makes the compiler copy the whole kernel argument to scratch
-// and index it there; chains of wave-uniform selects on constant indices stay in SGPRs.
-#define SEG_FIELD(p, ks, f) ((ks) == 0 ? (p).seg[0].f : (ks) == 1 ? (p).seg[1].f : (ks) == 2 ? (p).seg[2].f : (p).seg[3].f)
+#include "conv_common.h"
 
 template <typename T, typename TO, int BM, int BN, bool GNP>
 __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
@@ -529,8 +413,19 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParam
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
     const int n = (i % nv) * 4;
     const int64_t m = (int64_t)b * HW + i / nv;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < p.ksplit; ++z) a += *reinterpret_cast<const f32x4*>(p.partial + ((int64_t)z * M + m) * Cout + n);
+    // four independent partial sums: the slab loads of one output are all in flight together
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+    const float* src = p.partial + m * Cout + n;
+    const int64_t zs = M * Cout;
+    int z = 0;
+    for (; z + 3 < p.ksplit; z += 4) {
+      a0 += *reinterpret_cast<const f32x4*>(src + (z + 0) * zs);
+      a1 += *reinterpret_cast<const f32x4*>(src + (z + 1) * zs);
+      a2 += *reinterpret_cast<const f32x4*>(src + (z + 2) * zs);
+      a3 += *reinterpret_cast<const f32x4*>(src + (z + 3) * zs);
+    }
+    for (; z < p.ksplit; ++z) a0 += *reinterpret_cast<const f32x4*>(src + z * zs);
+    const f32x4 a = (a0 + a1) + (a2 + a3);
     float v[4] = {a[0], a[1], a[2], a[3]};
     conv_epilogue4<TO>(p, m, b, n, v);
     if (do_stat) {
@@ -611,6 +506,30 @@ extern "C" int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int
   return 0;
 }
 
+int fdbm_launch_conv_patch(const ConvParams& p, int dt_in, int dt_out, int th, hipStream_t st);   // conv_patch.hip
+
+// Which kernel runs a conv of this shape: kind 1 = halo-patch 3x3 kernel (conv_patch.hip, tile
+// th x 16 pixels x 128 channels), kind 0 = tap-outer implicit GEMM (this file).
+extern "C" int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int first_taps, int* kind,
+                                 int* th, int* bm, int* bn, int* ksplit) {
+  const int64_t M = (int64_t)B * H * W;
+  fdbm_conv_plan(M, Cout, nk, bm, bn, ksplit);
+  *kind = 0;
+  *th = 0;
+  static const char* force = getenv("FDBM_CONV_PATCH");     // experiments: "0" = never, unset = heuristic
+  if (force && force[0] == '0') return 0;
+  const int64_t tiles16 = (int64_t)B * (H / 16) * (W / 16) * ((Cout + 127) / 128);
+  // the halo-patch kernel wants >= 1 tile per CU (1-2 workgroups fit a CU); below that the
+  // tap-outer kernel's smaller tiles fill the chip better
+  if (first_taps == 9 && H % 8 == 0 && W % 16 == 0 && *ksplit == 1 && 2 * tiles16 >= 256) {
+    *kind = 1;
+    *th = (H % 16 == 0 && tiles16 >= 256) ? 16 : 8;
+    static const char* fth = getenv("FDBM_PATCH_TH");          // experiments
+    if (fth && fth[0] == '8') *th = 8;
+  }
+  return 0;
+}
+
 extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   FDBM_CHECK(a, "fdbm_conv_igemm: null args");
   FDBM_CHECK(a->nseg >= 1 && a->nseg <= FDBM_MAX_SEG, "fdbm_conv_igemm: nseg=%d out of range", a->nseg);
@@ -641,9 +560,10 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   p.res = a->res; p.scale = a->scale; p.out = a->out;
   p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.CoutPad = a->CoutPad;
   p.nk = nk;
-  int bm, bn, ks;
+  int bm, bn, ks, kind, th;
   const int64_t M = (int64_t)a->B * a->H * a->W;
-  fdbm_conv_plan(M, a->Cout, nk, &bm, &bn, &ks);
+  fdbm_conv_plan_ex(a->B, a->H, a->W, a->Cout, nk, a->seg[0].taps, &kind, &th, &bm, &bn, &ks);
+  if (kind == 1) bm = 16;          // a patch tile always lies inside one image
   if (!a->workspace || a->workspace_bytes <= 0) ks = 1;
   while (ks > 1 && (int64_t)ks * M * a->Cout * 4 > a->workspace_bytes) --ks;
   p.ksplit = ks;
@@ -677,6 +597,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     p.stat_out = a->stat_out; p.stat_G = a->stat_G; p.stat_nsplit = a->stat_nsplit;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (kind == 1) return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_BF16) return launch_conv_tile<bf16_t, bf16_t>(p, bm, bn, st);
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_F32) return launch_conv_tile<bf16_t, float>(p, bm, bn, st);
   return launch_conv_tile<float, float>(p, bm, bn, st);

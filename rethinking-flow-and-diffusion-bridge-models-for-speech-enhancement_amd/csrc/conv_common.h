@@ -1,0 +1,123 @@
+// conv_common.h - pieces shared by the convolution kernels (conv.hip: tap-outer implicit GEMM;
+// conv_patch.hip: halo-patch 3x3 kernel): kernel parameter block, MFMA wrappers, epilogue.
+#pragma once
+#include <type_traits>
+
+#include "common.h"
+
+template <typename T> struct Mfma;
+template <> struct Mfma<bf16_t> {
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                  *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
+  }
+};
+
+template <typename TO> struct OutVec;
+template <> struct OutVec<float> {
+  __device__ static __forceinline__ void load(const float* p, float* v) {
+    f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ static __forceinline__ void store(float* p, const float* v) {
+    f32x4 t = {v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  }
+};
+template <> struct OutVec<bf16_t> {
+  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
+    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+    v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+  }
+  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
+    bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = t;
+  }
+};
+
+struct ConvParams {
+  fdbm_conv_seg seg[FDBM_MAX_SEG];
+  int nseg;
+  const void* w;
+  const float* bias;
+  const float* tbias;
+  int tbias_stride;
+  const void* res;
+  float scale;
+  void* out;
+  int B, H, W, Cout, CoutPad;
+  int nk;
+  int ksplit;       // grid.z: k-steps are split over this many workgroups
+  float* partial;   // fp32 slabs [ksplit][M][Cout] when ksplit > 1
+  // GroupNorm(+SiLU) applied to the A operand while it is staged (segments with seg_gn >= 0;
+  // seg_gn = channel offset of the segment inside the normalised, virtually concatenated input)
+  const float* gn_sums;     // [B][gn_nsplit][gn_G][2] (sum, sumsq) or NULL
+  const float* gn_gamma;
+  const float* gn_beta;
+  int gn_nsplit, gn_G, gn_C, gn_silu;
+  double gn_inv_count;
+  float gn_eps;
+  int seg_gn[FDBM_MAX_SEG];
+  // Combine('sum') folded into the epilogue: out += comb_b[n] + comb_w[n][0..3] . pyr[m][0..3]
+  const float* comb_pyr;
+  const float* comb_w;
+  const float* comb_b;
+  // (sum, sumsq) of the stored output per (image, group of Cout/stat_G channels), accumulated
+  // with atomics into stat_out[B][stat_G][2] for the GroupNorm that consumes this tensor
+  float* stat_out;
+  int stat_G;
+  int stat_nsplit;   // stat_out is [B][stat_nsplit][stat_G][2]; a block adds into split blockIdx.x % nsplit
+};
+
+// sum over the 16 lanes of a DPP row (= the 16 pixels of an MFMA m-tile), every lane gets it:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - four VALU adds.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+  return v;
+}
+
+#define CONV_MAX_NB 4          // images one M tile may touch when a GN prologue / stats are on
+#define CONV_GN_MAXC 512
+
+// final value of 4 consecutive output channels of pixel m: bias, time-embedding bias, residual,
+// scale, Combine; stores and returns the stored (rounded) values in v.
+template <typename TO>
+__device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int64_t m, int64_t b, int n, float* v) {
+  const int Cout = p.Cout;
+  if (p.bias) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
+    v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+  }
+  if (p.tbias) {
+    const f32x4 tv = *reinterpret_cast<const f32x4*>(p.tbias + b * p.tbias_stride + n);
+    v[0] += tv[0]; v[1] += tv[1]; v[2] += tv[2]; v[3] += tv[3];
+  }
+  if (p.res) {
+    float r[4];
+    OutVec<TO>::load(reinterpret_cast<const TO*>(p.res) + m * Cout + n, r);
+    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+  }
+  v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale;
+  if (p.comb_pyr) {
+    const f32x4 q = *reinterpret_cast<const f32x4*>(p.comb_pyr + m * 4);
+    const f32x4 cb = *reinterpret_cast<const f32x4*>(p.comb_b + n);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const f32x4 w = *reinterpret_cast<const f32x4*>(p.comb_w + (int64_t)(n + r) * 4);
+      v[r] += cb[r] + (((w[0] * q[0] + w[1] * q[1]) + w[2] * q[2]) + w[3] * q[3]);
+    }
+  }
+  OutVec<TO>::store(reinterpret_cast<TO*>(p.out) + m * Cout + n, v);
+  if constexpr (sizeof(TO) == 2) {     // statistics are those of the STORED tensor
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (float)(bf16_t)v[r];
+  }
+}
+
+// p.seg[ks] with a run-time ks makes the compiler copy the whole kernel argument to scratch
+// and index it there; chains of wave-uniform selects on constant indices stay in SGPRs.
+#define SEG_FIELD(p, ks, f) ((ks) == 0 ? (p).seg[0].f : (ks) == 1 ? (p).seg[1].f : (ks) == 2 ? (p).seg[2].f : (p).seg[3].f)
+

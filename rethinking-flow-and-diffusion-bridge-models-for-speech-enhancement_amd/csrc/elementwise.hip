@@ -370,8 +370,8 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
   __syncthreads();
   const int ncg = nf / 8;   // 8 output channels per thread
   const int64_t total = (int64_t)B * H * W * ncg;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
   const int cg = (int)(idx % ncg);
   const int64_t p = idx / ncg;
   const int x = (int)(p % W);
@@ -411,6 +411,7 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
     Vec16<T>::store(dst, o);
     Vec16<T>::store(dst + 4, o + 4);
   }
+  }
 }
 
 extern "C" int fdbm_conv_stem(void* out, const float* in, const float* w, const float* bias, int B,
@@ -420,10 +421,12 @@ extern "C" int fdbm_conv_stem(void* out, const float* in, const float* w, const 
   const int64_t total = (int64_t)B * H * W * (nf / 8);
   const size_t smem = (size_t)nf * 37 * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
+  int gs = cdiv(total, 256);
+  if (gs > 1024) gs = 1024;            // grid-stride: the [36][nf] weight staging is paid 1024 times, not 4096
   if (dt_out == FDBM_BF16)
-    conv_stem_kernel<bf16_t><<<cdiv(total, 256), 256, smem, st>>>((bf16_t*)out, (const f32x4*)in, w, bias, B, H, W, nf);
+    conv_stem_kernel<bf16_t><<<gs, 256, smem, st>>>((bf16_t*)out, (const f32x4*)in, w, bias, B, H, W, nf);
   else if (dt_out == FDBM_F32)
-    conv_stem_kernel<float><<<cdiv(total, 256), 256, smem, st>>>((float*)out, (const f32x4*)in, w, bias, B, H, W, nf);
+    conv_stem_kernel<float><<<gs, 256, smem, st>>>((float*)out, (const f32x4*)in, w, bias, B, H, W, nf);
   else
     FDBM_CHECK(false, "fdbm_conv_stem: bad dtype %d", dt_out);
   FDBM_LAUNCH_CHECK("fdbm_conv_stem");

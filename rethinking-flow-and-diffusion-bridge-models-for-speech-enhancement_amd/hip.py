@@ -75,7 +75,8 @@ _SIGS = {
     "fdbm_memset_zero": [c_void_p, c_i64],
     "fdbm_run_program": [ctypes.POINTER(Op), c_int],
 }
-EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan"])
+EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan",
+                                "fdbm_conv_plan_ex"])
 
 
 def lib():
@@ -98,6 +99,8 @@ def lib():
         L.fdbm_conv_kc.restype = c_int
         L.fdbm_conv_plan.argtypes = [c_i64, c_int, c_int] + [ctypes.POINTER(c_int)] * 3
         L.fdbm_conv_plan.restype = c_int
+        L.fdbm_conv_plan_ex.argtypes = [c_int] * 6 + [ctypes.POINTER(c_int)] * 5
+        L.fdbm_conv_plan_ex.restype = c_int
         _lib = L
     return _lib
 
@@ -133,6 +136,13 @@ def conv_plan(M, cout, nk):
     bm, bn, ks = c_int(), c_int(), c_int()
     lib().fdbm_conv_plan(M, cout, nk, ctypes.byref(bm), ctypes.byref(bn), ctypes.byref(ks))
     return bm.value, bn.value, ks.value
+
+
+def conv_plan_ex(B, H, W, cout, nk, first_taps):
+    """-> dict(kind, th, bm, bn, ksplit); kind 1 = halo-patch kernel."""
+    v = [c_int() for _ in range(5)]
+    lib().fdbm_conv_plan_ex(B, H, W, cout, nk, first_taps, *[ctypes.byref(x) for x in v])
+    return dict(zip(("kind", "th", "bm", "bn", "ksplit"), [x.value for x in v]))
 
 
 def _dev_f32(w, device):

@@ -243,11 +243,26 @@ class Program:
         self.n_slots += 1
         return ptr
 
-    def tile_ok(self, HW, M, cout, nk):
-        """Can a conv of this shape carry a GN prologue / output statistics?  Its M tile must
-        lie in one image or cover at most 4 whole images (csrc/conv.hip CONV_MAX_NB)."""
-        bm, _, _ = hip.conv_plan(M, cout, nk)
+    def plan(self, a0, cout, segs):
+        return hip.conv_plan_ex(self.B, a0.H, a0.W, cout, self.nk_of(segs), segs[0][3])
+
+    def tile_ok(self, a0, cout, segs):
+        """Can this conv carry a GN prologue / output statistics?  Its M tile must lie in one
+        image (always true for the halo-patch kernel) or cover at most 4 whole images
+        (csrc/conv_common.h CONV_MAX_NB)."""
+        pl = self.plan(a0, cout, segs)
+        if pl["kind"] == 1:
+            return True
+        HW, bm = a0.H * a0.W, pl["bm"]
         return HW % 16 == 0 and (HW % bm == 0 or (bm % HW == 0 and bm // HW <= 4))
+
+    def prologue_pays(self, a0, cout, segs):
+        """GroupNorm+SiLU inside the conv: cheap in the halo-patch kernel (1.3-1.4x the tensor),
+        9x redundant in the tap-outer kernel - there only where the layer is latency-bound."""
+        pl = self.plan(a0, cout, segs)
+        if pl["kind"] == 1:
+            return True
+        return segs[0][3] == 1 or a0.H * a0.W <= self.FUSE_PROLOGUE_MAX_HW
 
     def nk_of(self, segs):
         kc = hip.conv_kc(self.dtc)
@@ -290,9 +305,10 @@ class Program:
         nk = sum(taps * ((cin + kc - 1) // kc) for (_, _, cin, taps) in segs)
         HW = a0.H * a0.W
         if want_stats and self.fused and (cout // want_stats) % 4 == 0 and cout % want_stats == 0 \
-                and self.tile_ok(HW, a0.M, cout, nk):
-            bm, _, _ = hip.conv_plan(a0.M, cout, nk)
-            nsp = max(1, min(16, (HW // bm) // 8))      # rows the blocks' atomics are spread over
+                and self.tile_ok(a0, cout, segs):
+            pl = self.plan(a0, cout, segs)
+            tile_px = pl["th"] * 16 if pl["kind"] == 1 else pl["bm"]
+            nsp = max(1, min(16, (HW // tile_px) // 8))      # rows the blocks' atomics are spread over
             slot = self.new_slot(nsp, want_stats)
             ca.stat_out, ca.stat_G, ca.stat_nsplit = slot, want_stats, nsp
             out.stats[want_stats] = (slot, nsp, HW * (cout // want_stats))
@@ -343,8 +359,8 @@ class Program:
         else:
             short_srcs = srcs
             segs0 = [(s, 0, s.C, 9) for s in srcs]
-            fuse = (self.fused and H * Wd <= self.FUSE_PROLOGUE_MAX_HW and in_ch <= 512
-                    and self.tile_ok(H * Wd, srcs[0].M, out_ch, self.nk_of(segs0)))
+            fuse = (self.fused and in_ch <= 512 and self.prologue_pays(srcs[0], out_ch, segs0)
+                    and self.tile_ok(srcs[0], out_ch, segs0))
             if fuse:
                 gn0 = (st0, W["gn0_w"], W["gn0_b"], G0, in_ch, True, len(srcs))
             else:
@@ -361,15 +377,6 @@ class Program:
             self.free_act(a0)
         st1, own1 = self.stats_for([h1], G1)
         segs1 = [(h1, 0, out_ch, 9)]
-        fuse1 = (self.fused and h1.H * h1.W <= self.FUSE_PROLOGUE_MAX_HW
-                 and self.tile_ok(h1.H * h1.W, h1.M, out_ch, self.nk_of(segs1) + len(short_srcs) * 8))
-        a1 = None
-        if fuse1:
-            gn1 = (st1, W["gn1_w"], W["gn1_b"], G1, out_ch, True, 1)
-        else:
-            gn1 = None
-            a1 = self.gn_apply([h1], st1, W["gn1_w"], W["gn1_b"], G1, True)
-            segs1 = [(a1, 0, out_ch, 9)]
         res = None
         if W["has_conv2"]:
             for s_ in short_srcs:
@@ -377,8 +384,11 @@ class Program:
         else:
             assert len(short_srcs) == 1 and short_srcs[0].C == out_ch
             res = short_srcs[0]
-        if fuse1 and not self.tile_ok(h1.H * h1.W, h1.M, out_ch, self.nk_of(segs1)):
-            # (the exact k-step count decides the tile; fall back rather than violate the contract)
+        fuse1 = self.fused and self.prologue_pays(h1, out_ch, segs1) and self.tile_ok(h1, out_ch, segs1)
+        a1 = None
+        if fuse1:
+            gn1 = (st1, W["gn1_w"], W["gn1_b"], G1, out_ch, True, 1)
+        else:
             gn1 = None
             a1 = self.gn_apply([h1], st1, W["gn1_w"], W["gn1_b"], G1, True)
             segs1[0] = (a1, 0, out_ch, 9)
@@ -399,7 +409,7 @@ class Program:
         st, own = self.stats_for([x], G)
         segs = [(x, 0, C, 1)]
         a = None
-        if self.fused and self.tile_ok(x.H * x.W, x.M, 3 * C, self.nk_of(segs)):
+        if self.fused and self.tile_ok(x, 3 * C, segs):
             gn = (st, W["gn_w"], W["gn_b"], G, C, False, 1)      # 1 tap: the prologue costs nothing extra
         else:
             gn = None
@@ -512,7 +522,7 @@ class Program:
                 self.free_act(pyramid)
             segs = [(h, 0, h.C, 9)]
             a = None
-            if self.fused and h.H * h.W <= self.FUSE_PROLOGUE_MAX_HW and self.tile_ok(h.H * h.W, h.M, IN_CH, self.nk_of(segs)):
+            if self.fused and self.prologue_pays(h, IN_CH, segs) and self.tile_ok(h, IN_CH, segs):
                 gn = (st, gw["w"], gw["b"], G, h.C, True, 1)
             else:
                 gn = None

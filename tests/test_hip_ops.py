@@ -250,6 +250,11 @@ CONV_CASES = [
     ("shortcut", 1, 8, 8, [128], 256, 9, dict(shortcut=[256, 128])),
     ("ragged_w", 1, 6, 10, [32], 32, 9, {}),
     ("big_m", 1, 64, 128, [64], 128, 9, {}),
+    ("patch_th8", 1, 128, 128, [64], 128, 9, dict(res=True, tbias=True)),      # halo-patch kernel, 8-row tiles
+    ("patch_th16_b2", 2, 256, 128, [64], 128, 9, {}),                            # 16-row tiles
+    ("patch_cat_short", 1, 64, 256, [128, 64], 128, 9, dict(shortcut=[128, 64])),
+    ("patch_head", 1, 128, 128, [128], 4, 9, dict(head=True)),
+    ("patch_c96", 1, 128, 128, [96], 192, 9, {}),
     ("mid_m_256", 1, 32, 32, [256], 256, 9, dict(res=True)),
 ]
 
@@ -302,6 +307,9 @@ FUSED_CASES = [
     ("cat_8x8", 2, 8, 8, [256, 128], 128, 32, 32, True, False),
     ("down_comb_32", 1, 32, 32, [128], 128, 32, 32, False, True),
     ("big_m_stats", 1, 64, 64, [64], 128, 16, 32, False, False),
+    ("patch_gn", 1, 128, 128, [128], 128, 32, 32, False, False),
+    ("patch_gn_cat", 2, 64, 128, [128, 64], 128, 32, 32, True, False),
+    ("patch_gn_comb", 1, 128, 128, [64], 128, 16, 32, False, True),
 ]
 
 

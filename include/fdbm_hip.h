@@ -92,7 +92,10 @@ int fdbm_conv_stem(void* out, const float* in, const float* w, const float* bias
 /* ------------------------------------------------------------------ GroupNorm
  * nn.GroupNorm(min(C/4,32), C, eps=1e-6) (layerspp.py:67,219,231; ncsnpp_v2.py:205,217)
  * over a VIRTUAL CONCAT of up to two NHWC tensors (torch.cat([h, hs.pop()], 1),
- * ncsnpp_v2.py:330).  Stage 1: per-(b, split, group) partial sums; stage 2: mean/rstd. */
+ * ncsnpp_v2.py:330).  Stage 1: per-(b, split, group) partial sums; stage 2: mean/rstd.
+ * bf16 tensors: float partials.  f32 tensors (parity mode): sums AND partials are fp64
+ * ([B][nsplit][G][2] doubles) because the one-pass variance cancels when |mean| >> std;
+ * every consumer takes such a buffer with nsplit NEGATED. */
 int fdbm_gn_stats(float* partial /*[B][nsplit][G][2]*/, const void* src0, int C0,
                   const void* src1, int C1, int B, int HW, int G, int nsplit, int dtype,
                   void* stream);
@@ -226,8 +229,7 @@ int fdbm_pad_spec(void* out, const void* in, int64_t rows, int T, int Tpad, int 
 
 /* ------------------------------------------------------------------ recorded programs
  * A backbone forward is a fixed list of the calls above.  The host records it once
- * (opcode + argument block per op) and replays it with one call; this is what
- * `fdbm_ncsnpp_forward(ctx, ...)` of SURVEY.md 8(b) amounts to. */
+ * (opcode + argument block per op) and replays it with one call (see fdbm_ncsnpp_forward). */
 typedef struct {
   int32_t opcode;        /* FDBM_OP_* */
   int32_t reserved;
@@ -252,6 +254,19 @@ typedef struct {
 
 int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream);
 int fdbm_run_program(const fdbm_op* ops_host, int n_ops, void* stream);
+
+/* ------------------------------------------------------------------ composed backbone
+ * s = dnn(x_t, y, t) (BridgeModel.forward, fdbm/model.py:356-357 -> NCSNpp_v2.forward,
+ * ncsnpp_v2.py:241-401) as ONE call: a context wraps a recorded program (copied) and the static
+ * device buffers it reads / writes.  x, y, out: complex64 [B][1][F][T]; log_t: f32 [B] (host-
+ * evaluated log of the model time, see fdbm_temb).  Passing the context's own buffers skips the
+ * copies.  One context per device per process; calls on a context are not re-entrant. */
+typedef struct fdbm_ncsnpp_ctx fdbm_ncsnpp_ctx;
+fdbm_ncsnpp_ctx* fdbm_ncsnpp_create(const fdbm_op* ops_host, int n_ops, void* x_in, void* y_in,
+                                    float* logt_in, void* s_out, int64_t n_complex, int B);
+void fdbm_ncsnpp_destroy(fdbm_ncsnpp_ctx* ctx);
+int fdbm_ncsnpp_forward(fdbm_ncsnpp_ctx* ctx, const void* x, const void* y, const float* log_t,
+                        void* out, void* stream);
 
 #ifdef __cplusplus
 }

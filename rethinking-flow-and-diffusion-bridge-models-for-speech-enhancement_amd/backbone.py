@@ -182,12 +182,11 @@ class HipNCSNpp:
             raise RuntimeError("HipNCSNpp.forward needs HIP tensors (no CPU fallback)")
         B, _, F, T = x.shape
         prog = self.program(B, F, T)
-        prog.x_in.copy_(x)
-        prog.y_in.copy_(y)
         # log t on the host: see fdbm_temb in include/fdbm_hip.h
-        prog.t_in.copy_(torch.log(t.detach().to(device="cpu", dtype=torch.float32).reshape(B)))
-        prog.run()
-        return prog.s_out.clone()
+        log_t = torch.log(t.detach().to(device="cpu", dtype=torch.float32).reshape(B)).to(self.device)
+        out = torch.empty_like(prog.s_out)
+        prog.forward_into(x.to(torch.complex64).contiguous(), y.to(torch.complex64).contiguous(), log_t, out)
+        return out
 
     def flops_per_forward(self, F=256, T=256):
         return 2 * self.spec.macs_per_forward(F, T)

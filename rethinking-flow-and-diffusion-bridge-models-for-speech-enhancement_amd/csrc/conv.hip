@@ -263,6 +263,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     for (int i = tid; i < nb * G; i += 256) {
       const int bl = i / G, g = i - bl * G;
       double a0 = 0.0, a1 = 0.0;
+      if (p.gn_nsplit < 0) {
+        const double* sd = reinterpret_cast<const double*>(p.gn_sums);
+        for (int sp = 0; sp < -p.gn_nsplit; ++sp) {
+          const double* q = sd + ((((int64_t)(b0 + bl)) * (-p.gn_nsplit) + sp) * G + g) * 2;
+          a0 += q[0];
+          a1 += q[1];
+        }
+      } else
       for (int sp = 0; sp < p.gn_nsplit; ++sp) {
         const float* q = p.gn_sums + ((((int64_t)(b0 + bl)) * p.gn_nsplit + sp) * G + g) * 2;
         a0 += (double)q[0];
@@ -572,7 +580,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   for (int s = 0; s < FDBM_MAX_SEG; ++s) p.seg_gn[s] = -1;
   if (a->gn_sums) {
     FDBM_CHECK(a->gn_gamma && a->gn_beta && a->gn_G > 0 && a->gn_G <= 32 && a->gn_C > 0 && a->gn_C <= CONV_GN_MAXC &&
-               a->gn_C % a->gn_G == 0 && a->gn_nsplit >= 1 && a->gn_count > 0,
+               a->gn_C % a->gn_G == 0 && a->gn_nsplit != 0 && a->gn_count > 0,
                "fdbm_conv_igemm: bad GroupNorm prologue arguments (G=%d C=%d nsplit=%d)", a->gn_G, a->gn_C, a->gn_nsplit);
     FDBM_CHECK(HW % 16 == 0 && (HW % bm == 0 || (bm % HW == 0 && bm / HW <= CONV_MAX_NB)),
                "fdbm_conv_igemm: GroupNorm prologue needs H*W (%d) to tile the %d-pixel M tile", HW, bm);

@@ -80,6 +80,14 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
       const int G = p.gn_G, C = p.gn_C;
       for (int g = tid; g < G; g += NTHR) {
         double a0 = 0.0, a1 = 0.0;
+        if (p.gn_nsplit < 0) {
+          const double* sd = reinterpret_cast<const double*>(p.gn_sums);
+          for (int sp = 0; sp < -p.gn_nsplit; ++sp) {
+            const double* q = sd + (((int64_t)b * (-p.gn_nsplit) + sp) * G + g) * 2;
+            a0 += q[0];
+            a1 += q[1];
+          }
+        } else
         for (int sp = 0; sp < p.gn_nsplit; ++sp) {
           const float* q = p.gn_sums + (((int64_t)b * p.gn_nsplit + sp) * G + g) * 2;
           a0 += (double)q[0];

@@ -11,14 +11,17 @@
 
 #define GN_MAXC 1024
 
-template <typename T>
-__global__ void __launch_bounds__(256) gn_stats_kernel(float* __restrict__ partial,
+// ACC = float (bf16 tensors: partial sums stored as float) or double (f32 parity mode: the
+// one-pass variance E[x^2] - mean^2 cancels when |mean| >> std, so sums AND the stored partials
+// are fp64 there; consumers see that as a negative nsplit).
+template <typename T, typename ACC>
+__global__ void __launch_bounds__(256) gn_stats_kernel(ACC* __restrict__ partial,
                                                        const T* __restrict__ src0, int C0,
                                                        const T* __restrict__ src1, int C1, int HW,
                                                        int G, int nsplit) {
   constexpr int VW = DT<T>::vecw;
-  __shared__ float s_part[2][256 * VW];   // per-thread channel sums
-  __shared__ float s_ch[2][GN_MAXC];      // per-channel sums
+  __shared__ ACC s_part[2][256 * VW];     // per-thread channel sums
+  __shared__ ACC s_ch[2][GN_MAXC];        // per-channel sums
   const int b = blockIdx.y, split = blockIdx.x;
   const int C = C0 + C1;
   const int per = (HW + nsplit - 1) / nsplit;
@@ -34,9 +37,9 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(float* __restrict__ parti
     const int ppi = 256 / nvec;             // pixels per block iteration
     const int v = threadIdx.x % nvec;
     const int pl = threadIdx.x / nvec;
-    float sum[VW], sq[VW];
+    ACC sum[VW], sq[VW];
 #pragma unroll
-    for (int k = 0; k < VW; ++k) sum[k] = sq[k] = 0.f;
+    for (int k = 0; k < VW; ++k) sum[k] = sq[k] = (ACC)0;
     if (pl < ppi) {
       const T* base = src + (int64_t)b * HW * Cs + v * VW;
       for (int p = p0 + pl; p < p1; p += ppi) {
@@ -44,8 +47,8 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(float* __restrict__ parti
         Vec16<T>::load(base + (int64_t)p * Cs, x);
 #pragma unroll
         for (int k = 0; k < VW; ++k) {
-          sum[k] += x[k];
-          sq[k] += x[k] * x[k];
+          sum[k] += (ACC)x[k];
+          sq[k] += (ACC)x[k] * (ACC)x[k];
         }
       }
     }
@@ -58,7 +61,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(float* __restrict__ parti
     __syncthreads();
     // channel c of this source: threads pl*nvec + c/VW, element c%VW, pl = 0..ppi-1
     for (int c = threadIdx.x; c < Cs; c += blockDim.x) {
-      float a0 = 0.f, a1 = 0.f;
+      ACC a0 = 0, a1 = 0;
       for (int q = 0; q < ppi; ++q) {
         const int th = q * nvec + c / VW;
         a0 += s_part[0][th * VW + c % VW];
@@ -71,12 +74,12 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(float* __restrict__ parti
   }
   const int cpg = C / G;
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    float a0 = 0.f, a1 = 0.f;
+    ACC a0 = 0, a1 = 0;
     for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
       a0 += s_ch[0][c];
       a1 += s_ch[1][c];
     }
-    float* dst = partial + (((int64_t)b * nsplit + split) * G + g) * 2;
+    ACC* dst = partial + (((int64_t)b * nsplit + split) * G + g) * 2;
     dst[0] = a0;
     dst[1] = a1;
   }
@@ -94,9 +97,9 @@ extern "C" int fdbm_gn_stats(float* partial, const void* src0, int C0, const voi
   dim3 grid(nsplit, B);
   hipStream_t st = (hipStream_t)stream;
   if (dtype == FDBM_BF16)
-    gn_stats_kernel<bf16_t><<<grid, 256, 0, st>>>(partial, (const bf16_t*)src0, C0, (const bf16_t*)src1, C1, HW, G, nsplit);
-  else if (dtype == FDBM_F32)
-    gn_stats_kernel<float><<<grid, 256, 0, st>>>(partial, (const float*)src0, C0, (const float*)src1, C1, HW, G, nsplit);
+    gn_stats_kernel<bf16_t, float><<<grid, 256, 0, st>>>(partial, (const bf16_t*)src0, C0, (const bf16_t*)src1, C1, HW, G, nsplit);
+  else if (dtype == FDBM_F32)   // fp64 partials: `partial` must hold B*nsplit*G*2 doubles; consumers get nsplit negated
+    gn_stats_kernel<float, double><<<grid, 256, 0, st>>>((double*)partial, (const float*)src0, C0, (const float*)src1, C1, HW, G, nsplit);
   else
     FDBM_CHECK(false, "fdbm_gn_stats: bad dtype %d", dtype);
   FDBM_LAUNCH_CHECK("fdbm_gn_stats");
@@ -109,10 +112,19 @@ __global__ void gn_finalize_kernel(float* __restrict__ mr, const float* __restri
   if (i >= B * G) return;
   const int b = i / G, g = i % G;
   double s0 = 0.0, s1 = 0.0;
+  if (nsplit < 0) {
+    const double* pd = reinterpret_cast<const double*>(partial);
+    for (int s = 0; s < -nsplit; ++s) {
+      const double* p = pd + (((int64_t)b * (-nsplit) + s) * G + g) * 2;
+      s0 += p[0];
+      s1 += p[1];
+    }
+  } else {
   for (int s = 0; s < nsplit; ++s) {
     const float* p = partial + (((int64_t)b * nsplit + s) * G + g) * 2;
     s0 += (double)p[0];
     s1 += (double)p[1];
+  }
   }
   const double mean = s0 * inv_count;
   double var = s1 * inv_count - mean * mean;
@@ -176,14 +188,14 @@ extern "C" int fdbm_gn_apply(void* out, const void* src0, int C0, const void* sr
   const int C = C0 + C1;
   FDBM_CHECK(C0 % vw == 0 && C1 % vw == 0 && C <= GN_MAXC && G > 0 && G <= 32 && C % G == 0,
              "fdbm_gn_apply: bad channels (%d,%d) G=%d", C0, C1, G);
-  FDBM_CHECK(nsplit >= 0 && (nsplit == 0 || count > 0), "fdbm_gn_apply: bad nsplit/count");
+  FDBM_CHECK(nsplit == 0 || count > 0, "fdbm_gn_apply: bad nsplit/count");
   const int64_t total = (int64_t)HW * (C / vw);
   int chunks = (int)((total + 2047) / 2048);
   if (chunks > 1024) chunks = 1024;
   if (chunks < 1) chunks = 1;
   dim3 grid(chunks, B);
   hipStream_t st = (hipStream_t)stream;
-  const double inv = nsplit > 0 ? 1.0 / (double)count : 0.0;
+  const double inv = nsplit != 0 ? 1.0 / (double)count : 0.0;
 #define GN_APPLY(TT, S) gn_apply_kernel<TT, S><<<grid, 256, 0, st>>>((TT*)out, (const TT*)src0, C0, (const TT*)src1, C1, stats, nsplit, inv, eps, gamma, beta, HW, G, chunks)
   if (dtype == FDBM_BF16) { if (silu) GN_APPLY(bf16_t, true); else GN_APPLY(bf16_t, false); }
   else if (dtype == FDBM_F32) { if (silu) GN_APPLY(float, true); else GN_APPLY(float, false); }

@@ -141,8 +141,8 @@ extern "C" int fdbm_resample2x(void* out_plain, void* out_act, const void* in, c
   FDBM_CHECK(in && (out_plain || out_act), "fdbm_resample2x: null pointer");
   FDBM_CHECK((out_act != nullptr) == (stats != nullptr), "fdbm_resample2x: out_act needs GroupNorm statistics (and vice versa)");
   FDBM_CHECK(!out_act || (gamma && beta && G > 0 && G <= 32 && C % G == 0 && C <= 1024), "fdbm_resample2x: bad GroupNorm arguments");
-  FDBM_CHECK(nsplit >= 0 && (nsplit == 0 || count > 0), "fdbm_resample2x: bad nsplit/count");
-  const double inv_count = nsplit > 0 ? 1.0 / (double)count : 0.0;
+  FDBM_CHECK(nsplit == 0 || count > 0, "fdbm_resample2x: bad nsplit/count");
+  const double inv_count = nsplit != 0 ? 1.0 / (double)count : 0.0;
   const int vw = dtype == FDBM_BF16 ? 8 : 4;
   FDBM_CHECK(C % vw == 0, "fdbm_resample2x: C=%d must be a multiple of %d", C, vw);
   FDBM_CHECK(up || (H % 2 == 0 && W % 2 == 0), "fdbm_resample2x: downsampling needs even H, W (got %d x %d)", H, W);

@@ -89,3 +89,59 @@ extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* stream) {
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------
+// composed backbone entry: a context = a recorded program + its static I/O buffers
+// ---------------------------------------------------------------------------------
+struct fdbm_ncsnpp_ctx {
+  fdbm_op* ops;
+  int n_ops;
+  void* x_in;
+  void* y_in;
+  float* logt_in;
+  void* s_out;
+  int64_t n_complex;   // complex64 elements of x / y / s (B * F * T)
+  int B;
+};
+
+extern "C" fdbm_ncsnpp_ctx* fdbm_ncsnpp_create(const fdbm_op* ops_host, int n_ops, void* x_in, void* y_in,
+                                               float* logt_in, void* s_out, int64_t n_complex, int B) {
+  if (!ops_host || n_ops <= 0 || !x_in || !y_in || !logt_in || !s_out || n_complex <= 0 || B <= 0) {
+    fdbm_set_error("fdbm_ncsnpp_create: bad arguments");
+    return nullptr;
+  }
+  fdbm_ncsnpp_ctx* c = new fdbm_ncsnpp_ctx;
+  c->ops = new fdbm_op[n_ops];
+  memcpy(c->ops, ops_host, sizeof(fdbm_op) * (size_t)n_ops);
+  c->n_ops = n_ops; c->x_in = x_in; c->y_in = y_in; c->logt_in = logt_in; c->s_out = s_out;
+  c->n_complex = n_complex; c->B = B;
+  return c;
+}
+
+extern "C" void fdbm_ncsnpp_destroy(fdbm_ncsnpp_ctx* c) {
+  if (!c) return;
+  delete[] c->ops;
+  delete c;
+}
+
+// s = dnn(x, y, t): device pointers (complex64 [B][1][F][T] x2, f32 log t [B], complex64 out);
+// x / y / log_t / out may be the context's own static buffers (then no copy is enqueued).
+extern "C" int fdbm_ncsnpp_forward(fdbm_ncsnpp_ctx* c, const void* x, const void* y, const float* log_t,
+                                   void* out, void* stream) {
+  FDBM_CHECK(c && x && y && log_t && out, "fdbm_ncsnpp_forward: null argument");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t nb = (size_t)c->n_complex * 8;
+  hipError_t e = hipSuccess;
+  if (x != c->x_in) e = hipMemcpyAsync(c->x_in, x, nb, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess && y != c->y_in) e = hipMemcpyAsync(c->y_in, y, nb, hipMemcpyDeviceToDevice, st);
+  if (e == hipSuccess && log_t != c->logt_in)
+    e = hipMemcpyAsync(c->logt_in, log_t, sizeof(float) * (size_t)c->B, hipMemcpyDeviceToDevice, st);
+  FDBM_CHECK(e == hipSuccess, "fdbm_ncsnpp_forward: input copy failed: %s", hipGetErrorString(e));
+  const int rc = fdbm_run_program(c->ops, c->n_ops, stream);
+  if (rc) return rc;
+  if (out != c->s_out) {
+    e = hipMemcpyAsync(out, c->s_out, nb, hipMemcpyDeviceToDevice, st);
+    FDBM_CHECK(e == hipSuccess, "fdbm_ncsnpp_forward: output copy failed: %s", hipGetErrorString(e));
+  }
+  return 0;
+}

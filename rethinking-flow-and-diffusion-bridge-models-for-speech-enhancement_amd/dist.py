@@ -1,0 +1,63 @@
+"""Data-parallel sharding of utterances over ranks, plus the one collective of the path.
+
+The reference runs one independent process per GPU over contiguous chunks of the file list and
+never communicates (infer_folder.py:150-153,200-230).  Here: one process per GPU under
+torch.distributed (backend "nccl" = RCCL over xGMI on ROCm, "gloo" in the CPU tests), strided
+index sharding so ranks finish together when lengths are sorted, and ONE gather of the enhanced
+spectrograms to rank 0 per batch (526 KB per 4 s clip) - nothing else crosses the links.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def split_list(lst, n):
+    """The reference's contiguous split (infer_folder.py:150-153): ceil(len/n)-sized chunks."""
+    k = (len(lst) + n - 1) // n if n > 0 else len(lst)
+    return [lst[i * k:(i + 1) * k] for i in range(n)]
+
+
+def shard_indices(n_items, rank=None, world_size=None, contiguous=False):
+    """Indices of the utterances this rank enhances."""
+    r, w = world()
+    rank = r if rank is None else rank
+    world_size = w if world_size is None else world_size
+    if contiguous:
+        return split_list(list(range(n_items)), world_size)[rank]
+    return list(range(rank, n_items, world_size))
+
+
+def gather_spectrograms(X, dst=0):
+    """Gather complex spectrogram batches [n_r, 1, F, T] of every rank to `dst`.
+    Ranks may hold different n_r (ragged tail): sizes are exchanged first.  Returns the list of
+    per-rank tensors on `dst`, None elsewhere.  Single process: [X]."""
+    rank, w = world()
+    if w == 1:
+        return [X]
+    xr = torch.view_as_real(X.contiguous())
+    n = torch.tensor([xr.shape[0]], dtype=torch.int64, device=xr.device)
+    sizes = [torch.zeros_like(n) for _ in range(w)]
+    dist.all_gather(sizes, n)
+    nmax = int(max(int(s.item()) for s in sizes))
+    pad = torch.zeros((nmax,) + tuple(xr.shape[1:]), dtype=xr.dtype, device=xr.device)
+    pad[: xr.shape[0]] = xr
+    bufs = [torch.empty_like(pad) for _ in range(w)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dst)
+    if rank != dst:
+        return None
+    return [torch.view_as_complex(b[: int(s.item())].contiguous()) for b, s in zip(bufs, sizes)]
+
+
+def interleave(per_rank, n_items):
+    """Undo the strided sharding: per_rank[r][i] is utterance r + i*W."""
+    w = len(per_rank)
+    out = [None] * n_items
+    for r, chunk in enumerate(per_rank):
+        for i in range(chunk.shape[0]):
+            out[r + i * w] = chunk[i]
+    return out

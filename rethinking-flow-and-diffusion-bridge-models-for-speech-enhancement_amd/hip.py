@@ -76,7 +76,8 @@ _SIGS = {
     "fdbm_run_program": [ctypes.POINTER(Op), c_int],
 }
 EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan",
-                                "fdbm_conv_plan_ex"])
+                                "fdbm_conv_plan_ex", "fdbm_ncsnpp_create", "fdbm_ncsnpp_destroy",
+                                "fdbm_ncsnpp_forward"])
 
 
 def lib():
@@ -101,6 +102,12 @@ def lib():
         L.fdbm_conv_plan.restype = c_int
         L.fdbm_conv_plan_ex.argtypes = [c_int] * 6 + [ctypes.POINTER(c_int)] * 5
         L.fdbm_conv_plan_ex.restype = c_int
+        L.fdbm_ncsnpp_create.argtypes = [ctypes.POINTER(Op), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int]
+        L.fdbm_ncsnpp_create.restype = c_void_p
+        L.fdbm_ncsnpp_destroy.argtypes = [c_void_p]
+        L.fdbm_ncsnpp_destroy.restype = None
+        L.fdbm_ncsnpp_forward.argtypes = [c_void_p] * 6
+        L.fdbm_ncsnpp_forward.restype = c_int
         _lib = L
     return _lib
 

@@ -218,10 +218,11 @@ class Program:
         HW = a0.H * a0.W
         C = a0.C + (a1.C if a1 else 0)
         nsplit = max(1, min(HW, 64, (HW * C) // 32768))
-        partial = self.new_f32(self.B * nsplit * G * 2)
+        f64 = a0.dtype == torch.float32        # f32 tensors: fp64 partial sums (see csrc/groupnorm.hip)
+        partial = self.new_f32(self.B * nsplit * G * 2 * (2 if f64 else 1))
         self.emit(hip.OP_GN_STATS, [partial.data_ptr(), a0.ptr, a0.C, a1.ptr if a1 else 0,
                                     a1.C if a1 else 0, self.B, HW, G, nsplit, hip.dt_code(a0.dtype)])
-        return (partial, nsplit, HW * (C // G))
+        return (partial, -nsplit if f64 else nsplit, HW * (C // G))
 
     def gn_apply(self, srcs, st, gamma, beta, G, silu):
         a0 = srcs[0]
@@ -559,6 +560,27 @@ class Program:
                 arr[i].farg[j] = v
         self.op_array = arr
         self.n_ops = n
+        L = hip.lib()
+        self.ctx = L.fdbm_ncsnpp_create(arr, n, self.x_in.data_ptr(), self.y_in.data_ptr(), self.t_in.data_ptr(),
+                                        self.s_out.data_ptr(), self.x_in.numel(), self.B)
+        if not self.ctx:
+            raise RuntimeError("fdbm_ncsnpp_create failed: " + L.fdbm_last_error().decode())
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                hip.lib().fdbm_ncsnpp_destroy(self.ctx)
+                self.ctx = None
+        except Exception:
+            pass
+
+    def forward_into(self, x, y, log_t, out):
+        """The composed C entry: copies (if needed) + the whole recorded forward, one call."""
+        L = hip.lib()
+        rc = L.fdbm_ncsnpp_forward(self.ctx, x.data_ptr(), y.data_ptr(), log_t.data_ptr(), out.data_ptr(),
+                                   hip.stream_ptr())
+        if rc:
+            raise RuntimeError("fdbm_ncsnpp_forward failed: " + L.fdbm_last_error().decode())
 
     # ---- execution ---------------------------------------------------------------------
     def run(self):

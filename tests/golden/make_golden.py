@@ -238,6 +238,8 @@ def gen_samplers():
              dict(predictor_name="euler_maruyama", corrector_name="langevin", corrector_steps=1, snr=0.3, denoise=True)),
             ("sb_bb_ode_int", dict(path="sb", noise_schedule="bb", N=5, sampler_type="ode_int"),
              dict(rtol=1e-2, atol=1e-2)),
+            ("fm_ot_ode_int", dict(path="fm", noise_schedule="ot", N=5, sampler_type="ode_int"),
+             dict(rtol=1e-2, atol=1e-2)),
             ]
     for tag, bkw, skw in runs:
         br = Bridge(**bkw)

@@ -110,11 +110,12 @@ def _gn_mr(x_list, G):
     C1 = a1.shape[3] if a1 is not None else 0
     HW = H * W
     nsplit = max(1, min(HW, 7))
-    partial = torch.empty(B * nsplit * G * 2, device=DEV)
+    f64 = a0.dtype == torch.float32           # f32 tensors: fp64 partials, consumers get -nsplit
+    partial = torch.empty(B * nsplit * G * 2, device=DEV, dtype=torch.float64 if f64 else torch.float32)
     mr = torch.empty(B, G, 2, device=DEV)
     dtc = hip.dt_code(a0.dtype)
     hip.call("fdbm_gn_stats", hip.ptr(partial), hip.ptr(a0), C0, hip.ptr(a1), C1, B, HW, G, nsplit, dtc)
-    hip.call("fdbm_gn_finalize", hip.ptr(mr), hip.ptr(partial), B, nsplit, G, HW * ((C0 + C1) // G), 1e-6)
+    hip.call("fdbm_gn_finalize", hip.ptr(mr), hip.ptr(partial), B, -nsplit if f64 else nsplit, G, HW * ((C0 + C1) // G), 1e-6)
     return mr
 
 
@@ -142,10 +143,11 @@ def test_groupnorm(dtype, tol, C0, C1, G):
     assert (nchw(out) - ref).abs().max() < tol
     # same thing straight from the partial sums (what the recorded programs do)
     nsplit = 5
-    partial = torch.empty(B * nsplit * G * 2, device=DEV)
+    f64 = dtype == torch.float32
+    partial = torch.empty(B * nsplit * G * 2, device=DEV, dtype=torch.float64 if f64 else torch.float32)
     hip.call("fdbm_gn_stats", hip.ptr(partial), hip.ptr(d0), C0, hip.ptr(d1), C1, B, H * W, G, nsplit, hip.dt_code(dtype))
     out2 = torch.empty_like(out)
-    hip.call("fdbm_gn_apply", hip.ptr(out2), hip.ptr(d0), C0, hip.ptr(d1), C1, hip.ptr(partial), nsplit,
+    hip.call("fdbm_gn_apply", hip.ptr(out2), hip.ptr(d0), C0, hip.ptr(d1), C1, hip.ptr(partial), -nsplit if f64 else nsplit,
              H * W * ((C0 + C1) // G), 1e-6, hip.ptr(gd), hip.ptr(bd), B, H * W, G, 1, hip.dt_code(dtype))
     assert (nchw(out2) - ref).abs().max() < tol
 

@@ -1,0 +1,146 @@
+"""Host-side logic on CPU: registries, bridge coefficient tables (bit-exact with the reference's,
+tests/golden/coeffs.npz), sampler drivers with a plain callable model (vs the oracle), error
+behaviour, architecture bookkeeping, and that the C-ABI library loads and exports every symbol the
+header declares (no compute calls here: no GPU)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import fdbm_amd
+from fdbm_amd import hip
+from fdbm_amd.arch import Spec, VARIANTS
+from fdbm_amd.program import count_macs
+from fdbm_amd.registry import Registry
+from oracle import sampler as osamp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_behaviour():
+    r = Registry("Thing")
+
+    @r.register("a")
+    class A:
+        pass
+
+    assert r.get_by_name("a") is A and r.get_all_names() == ["a"]
+    with pytest.warns(UserWarning):
+        @r.register("a")
+        class A2:
+            pass
+    assert r.get_by_name("a") is A2
+    with pytest.raises(ValueError):
+        r.get_by_name("missing")
+    assert set(fdbm_amd.BridgeRegistry.get_all_names()) == {"sb", "fm"}
+    assert set(fdbm_amd.BackboneRegistry.get_all_names()) == set(VARIANTS)
+    assert {"euler_maruyama", "none"} <= set(fdbm_amd.PredictorRegistry.get_all_names())
+    assert {"langevin", "ald", "none"} <= set(fdbm_amd.CorrectorRegistry.get_all_names())
+
+
+@pytest.mark.parametrize("path,sched", [("sb", "bb"), ("sb", "ve"), ("sb", "vp"), ("sb", "gmax"), ("fm", "ot")])
+def test_coefficient_tables_bit_exact(golden, path, sched):
+    g = golden("coeffs")
+    for N in (5, 30, 100):
+        br = fdbm_amd.Bridge(path, N=N, noise_schedule=sched)
+        key = f"{path}_{sched}_N{N}"
+        assert np.array_equal(br.time_grid(N + 1).numpy(), g[key + "_ts"])
+        tab, t_model = br.ei_weight_table("ode", 1)
+        assert np.array_equal(tab[:, :, 0].numpy(), g[key + "_ode_ei"]), key
+        assert np.array_equal(t_model.numpy(), g[key + "_ts"][:-1])
+        if path == "sb":
+            tab, _ = br.ei_weight_table("sde", 1)
+            ref = g[key + "_sde_ei"].copy()
+            ref[-1, 2] = 0.0                                  # last step: w_z = 0 (bridge.py:105-106)
+            assert np.array_equal(tab[:, :, 0].numpy(), ref), key
+            ts = torch.from_numpy(g[key + "_ts"])
+            w = torch.stack([torch.cat(list(br.path.sde_weights(ts[i] * torch.ones(1))) +
+                                       list(br.path.ode_weights(ts[i] * torch.ones(1)))) for i in range(N)])
+            assert np.array_equal(w.numpy(), g[key + "_sde_ode_w"]), key
+        pp = torch.stack([torch.stack(br.path.path_param(torch.from_numpy(g[key + "_ts"])[i] * torch.ones(1))).flatten()
+                          for i in range(N + 1)])
+        assert np.array_equal(pp.numpy(), g[key + "_path_param"])
+
+
+def _toy_model(xt, y, t):
+    # any callable (xt, y, t) -> s: a cheap smooth map so the drivers can be checked on CPU
+    tt = t.to(xt.device)[:, None, None, None]
+    return 0.6 * y + 0.3 * xt * torch.cos(tt) + 0.05 * torch.roll(xt, 1, dims=-1)
+
+
+@pytest.mark.parametrize("kind,path,pkw", [("ode_ei", "sb", dict(noise_schedule="bb")), ("ode_ei", "fm", {}),
+                                           ("sde_ei", "sb", dict(noise_schedule="ve")),
+                                           ("pc", "sb", dict(noise_schedule="bb"))])
+def test_sampler_drivers_match_oracle_on_cpu(kind, path, pkw):
+    g = torch.Generator().manual_seed(3)
+    y = torch.view_as_complex(torch.randn(2 if kind != "pc" else 1, 1, 9, 8, 2, generator=g))
+    br = fdbm_amd.Bridge(path, N=6, sampler_type=kind, **pkw)
+    skw = dict(predictor_name="euler_maruyama", corrector_name="ald", snr=0.4, denoise=False) if kind == "pc" else {}
+    out = br.sampler(_toy_model, y, generator=torch.Generator().manual_seed(5), **skw)
+    smp = osamp.Sampler(path, N=6, **pkw)
+    okw = dict(corrector="ald", snr=0.4, denoise=False) if kind == "pc" else {}
+    ref = getattr(smp, kind)(_toy_model, y, torch.Generator().manual_seed(5), **okw)
+    assert (out - ref).abs().max() < 1e-5
+    # injected noise wins over the generator; default noise is drawn on the tensor's device
+    z0 = torch.zeros_like(y)
+    a = br.sampler(_toy_model, y, prior_noise=z0, step_noise=lambda i: z0, **skw)
+    b = br.sampler(_toy_model, y, prior_noise=z0, step_noise=[z0] * 64, **skw)
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
+
+
+def test_reference_defects_mirrored():
+    y = torch.zeros(1, 1, 5, 4, dtype=torch.complex64)
+    br = fdbm_amd.Bridge("sb", N=3, sampler_type="pc")
+    with pytest.raises(ValueError):                    # default predictor 'reverse_diffusion' is unregistered
+        br.sampler(_toy_model, y)
+    br = fdbm_amd.Bridge("fm", N=3, sampler_type="sde_ei")
+    with pytest.raises(NotImplementedError):           # the fm path defines no SDE
+        br.sampler(_toy_model, y)
+    br = fdbm_amd.Bridge("sb", N=3, sampler_type="nope")
+    with pytest.raises(ValueError):
+        br.sampler(_toy_model, y)
+    assert fdbm_amd.Bridge("sb", T=0.5).path.T == 1.0  # T is dropped by the sb path, as in the reference
+    x = br.prior_sampling(torch.ones(2, 1, 3, 3, dtype=torch.complex64))
+    assert torch.equal(torch.view_as_real(x), torch.view_as_real(torch.ones(2, 1, 3, 3, dtype=torch.complex64)))
+
+
+def test_architecture_bookkeeping():
+    counts = {"ncsnpp_v2": 65_590_822, "ncsnpp_v2_5M": 5_216_762, "ncsnpp_v2_16M": 16_241_190, "ncsnpp_v2_37M": 36_926_630}
+    for name, kw in VARIANTS.items():
+        assert Spec(**kw).num_params() == counts[name]
+    spec = Spec(**VARIANTS["ncsnpp_v2"])
+    assert len(spec.mods) == 77 and len(spec.param_shapes()) == 647
+    assert count_macs(spec, 256, 256) == 266_073_636_864
+    assert count_macs(spec, 256, 512) > 2 * count_macs(spec, 256, 256) - 10**9
+
+
+def test_complex_randn_matches_torch():
+    a = fdbm_amd.complex_randn((2, 1, 5, 7), torch.Generator().manual_seed(11))
+    torch.manual_seed(11)
+    b = torch.randn_like(torch.zeros(2, 1, 5, 7, dtype=torch.complex64))
+    assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(REPO, "include", "fdbm_hip.h")).read()
+    declared = set(re.findall(r"\b(fdbm_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fdbm_conv_seg", "fdbm_conv_args", "fdbm_op"}
+    assert len(declared) >= 25
+    L = ctypes.CDLL(hip.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(L, n)]
+    assert not missing, missing
+    assert set(hip.EXPORTS) <= declared | {"fdbm_last_error"}
+    assert hip.lib().fdbm_version() >= 1
+
+
+def test_no_cpu_fallback():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        fdbm_amd.BackboneRegistry.get_by_name("ncsnpp_v2_5M")()
+    from fdbm_amd.frontend import SpecFrontend
+    with pytest.raises(RuntimeError):
+        SpecFrontend()

@@ -157,9 +157,9 @@ def test_samplers(golden, tag, path, pkw, N, kind, skw):
 def test_sampler_ode_int(golden):
     g = golden("samplers")
     model, _ = _model("v2_5M")
-    smp = osamp.Sampler("sb", N=5, noise_schedule="bb")
+    smp = osamp.Sampler("fm", N=5)
     out = smp.ode_int(model, T(g["y"]), torch.Generator().manual_seed(1234), rtol=1e-2, atol=1e-2)
-    assert maxabs(out, g["sb_bb_ode_int"]) < 2e-3     # adaptive RK45: step decisions amplify fp noise
+    assert maxabs(out, g["fm_ot_ode_int"]) < 2e-3     # adaptive RK45: step decisions amplify fp noise
 
 
 def test_sampler_batched(golden):

@@ -7,6 +7,10 @@ from fdbm_amd.arch import VARIANTS
 from fdbm_amd.backbone import HipNCSNpp
 
 G = lambda n: dict(np.load(os.path.join("tests/golden", n + ".npz")))
+A = G("fp64_arbiter")
+def rep(tag, out, ref, arb):
+    o, r, a = out.numpy(), np.asarray(ref), np.asarray(arb)
+    print(f"  {tag:28s} |hip-ref| {np.abs(o-r).max():.2e}  |hip-fp64| {np.abs(o-a).max():.2e}  |ref-fp64| {np.abs(r-a).max():.2e}  rms: hip-fp64 {np.sqrt((np.abs(o-a)**2).mean()):.2e} ref-fp64 {np.sqrt((np.abs(r-a)**2).mean()):.2e}")
 T = lambda a: torch.from_numpy(np.asarray(a))
 MINI64 = dict(nf=64, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,))
 full = "--full" in sys.argv
@@ -28,6 +32,7 @@ for dtype in (torch.float32, torch.bfloat16):
         br = fdbm_amd.Bridge(**bkw)
         out = br.sampler(net, y, generator=torch.Generator().manual_seed(1234)).cpu()
         print(f"  {tag:18s} {str(dtype):15s} max-abs {float((out-T(g[tag])).abs().max()):.3e}  ref max {float(T(g[tag]).abs().max()):.3f}")
+        if dtype == torch.float32: rep(tag, out, g[tag], A[tag])
     print("  reference self-noise (8 vs 1 thread):", float((T(g['sb_bb_ode_ei_N5']) - T(g['sb_bb_ode_ei_N5_1thread'])).abs().max()))
     if full:
         net = HipNCSNpp(dtype=dtype, device="cuda:0", **VARIANTS["ncsnpp_v2"])
@@ -38,3 +43,4 @@ for dtype in (torch.float32, torch.bfloat16):
             br = fdbm_amd.Bridge(N=30, sampler_type="ode_ei", **bkw)
             out = br.sampler(net, T(g["y"]).cuda(), generator=torch.Generator().manual_seed(4321)).cpu()
             print(f"full {key} {dtype} max-abs {float((out-T(g[key])).abs().max()):.3e} ref max {float(T(g[key]).abs().max()):.3f}")
+            if dtype == torch.float32: rep("full " + key, out, g[key], A["full_" + key])

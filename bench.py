@@ -106,12 +106,15 @@ def time_conv_launches(net, B, F, T, reps=3):
         for k, (a, b) in enumerate(evs):
             best[k] = min(best[k], a.elapsed_time(b))
         fwd_ms = min(fwd_ms, e0.elapsed_time(e1))
-    # algorithmic flops of each conv launch (all segments), whole batch
-    flops = []
+    # algorithmic flops of each conv launch (all segments), whole batch; which kernel runs it
+    flops, kinds = [], []
+    kc = hip.conv_kc(prog.dtc)
     for ca in prog.keep_conv:
         k = sum(ca.seg[s].cin * ca.seg[s].taps for s in range(ca.nseg))
         flops.append(2.0 * ca.B * ca.H * ca.W * ca.Cout * k)
-    return best, flops, fwd_ms, prog
+        nk = sum(ca.seg[s].taps * ((ca.seg[s].cin + kc - 1) // kc) for s in range(ca.nseg))
+        kinds.append(hip.conv_plan_ex(ca.B, ca.H, ca.W, ca.Cout, nk, ca.seg[0].taps)["kind"])
+    return best, flops, kinds, fwd_ms, prog
 
 
 def cpu_baseline(n_forwards, n_steps):
@@ -229,18 +232,34 @@ def main():
         "whole_step_tflops": world * args.batch * args.N * flops_fwd / (elapsed / args.steps) / 1e12,
     }
 
-    # ---- roofline of the dominant kernel (conv_igemm_kernel) ---------------------------
-    times, flops, fwd_ms, prog = time_conv_launches(hp.net, args.batch, F, T)
-    t_conv = sum(times) * 1e-3
-    achieved = sum(flops) / t_conv / 1e12
+    # ---- roofline of the dominant kernel ---------------------------------------------------
+    # conv_patch_kernel (3x3 convs of the large feature maps) carries most of the algorithmic
+    # flops; its achieved rate = its launches' algorithmic flops / their HIP-event durations.
+    # all_conv = the same over every convolution launch (both kernels), i.e. incl. the
+    # latency-bound small-map layers.
+    times, flops, kinds, fwd_ms, prog = time_conv_launches(hp.net, args.batch, F, T)
     peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+    sel = [i for i, k in enumerate(kinds) if k == 1] or list(range(len(times)))
+    t_dom = sum(times[i] for i in sel) * 1e-3
+    f_dom = sum(flops[i] for i in sel)
+    achieved = f_dom / t_dom / 1e12
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r01", "c_pmc_traffic_b1_bf16.json")
+    if args.batch == 1 and args.dtype == "bf16" and os.path.exists(pmc):
+        try:        # measured offline with rocprofv3 --pmc (tools/pmc_workload.py), bytes per launch
+            traffic = json.load(open(pmc))["conv_patch_kernel"]["hbm_bytes_per_launch_corrected"]
+        except Exception:
+            traffic = None
+    t_conv = sum(times) * 1e-3
     result["roofline"] = {
-        "bound": "mfma", "kernel": "conv_igemm_kernel", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-        "frac": achieved / peak, "traffic": None,
-        "launches_per_forward": len(times), "avg_launch_us": 1e3 * sum(times) / len(times),
-        "algorithmic_gflop_per_launch_avg": sum(flops) / len(times) / 1e9,
-        "conv_ms_per_forward": 1e3 * t_conv, "forward_ms_eager": fwd_ms,
-        "forward_ms_in_graph": 1e3 * elapsed / args.steps / args.N,
+        "bound": "mfma", "kernel": "conv_patch_kernel" if any(k == 1 for k in kinds) else "conv_igemm_kernel",
+        "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+        "launches_per_forward": len(sel), "avg_launch_us": 1e3 * t_dom / len(sel) * 1e0,
+        "algorithmic_gflop_per_launch_avg": f_dom / len(sel) / 1e9,
+        "share_of_forward_flops": f_dom / sum(flops),
+        "all_conv": {"achieved": sum(flops) / t_conv / 1e12, "frac": sum(flops) / t_conv / 1e12 / peak,
+                     "launches_per_forward": len(times), "ms_per_forward": 1e3 * t_conv},
+        "forward_ms_eager": fwd_ms, "forward_ms_in_graph": 1e3 * elapsed / args.steps / args.N,
     }
 
     if not args.no_extras:

@@ -23,8 +23,12 @@
 
 #include "conv_common.h"
 
-template <typename T, typename TO, int BM, int BN, bool GNP>
-__global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
+// KG = k-groups: the workgroup has KG x 4 waves; group g runs the same 4-wave tile code on its
+// own slice of the k-steps with its own LDS buffers, and the groups' accumulators are summed
+// through LDS at the end (split-K inside the workgroup: KG x the loads in flight and MFMA issue
+// per output tile, no slab traffic) - for layers with too few output tiles to fill the chip.
+template <typename T, typename TO, int BM, int BN, bool GNP, int KG>
+__global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p) {
   constexpr int KC = 128 / (int)sizeof(T);   // elements per k-step row
   constexpr int VW = 16 / (int)sizeof(T);    // elements per 16-byte chunk
   constexpr int WTM = BM / 2, WTN = BN / 2;  // wave tile (4 waves as 2 x 2)
@@ -35,7 +39,9 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-  const int tid = threadIdx.x;
+  constexpr int NTHR = 256 * KG;
+  const int grp = KG > 1 ? __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8) : 0;   // wave-uniform
+  const int tid = threadIdx.x & 255;            // thread within its k-group
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -44,11 +50,15 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   const int64_t M = (int64_t)p.B * HW;
   const int64_t m0 = (int64_t)blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
+  unsigned char* gsm = smem + grp * (2 * BUF);  // this group's two LDS buffers
 
-  // ---- split-K: this block owns k-steps [kbeg, kend) ------------------------------------
+  // ---- split-K: the block owns k-steps [zb, ze), this group [kbeg, kend) of them --------------
   const int kper = (p.nk + p.ksplit - 1) / p.ksplit;
-  const int kbeg = blockIdx.z * kper;
-  const int kend = min(p.nk, kbeg + kper);
+  const int zb = blockIdx.z * kper;
+  const int ze = min(p.nk, zb + kper);
+  const int gper = (max(ze - zb, 0) + KG - 1) / KG;      // loop length, the same for every group
+  const int kbeg = min(ze, zb + grp * gper);
+  const int kend = min(ze, kbeg + gper);
   const int nloc = kend - kbeg;
 
   // ---- loader mapping: thread -> (16-byte chunk, rows lrow + 32 i) ------------------
@@ -70,14 +80,14 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   }
 
   // ---- GroupNorm prologue table + output-statistics scratch (after the two LDS buffers) ----
-  float2* s_gn = reinterpret_cast<float2*>(smem + 2 * BUF);                  // [nb][gn_C] {scale, shift}
-  float* s_stat = reinterpret_cast<float*>(smem + 2 * BUF + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0));  // [nb][32][2]
+  float2* s_gn = reinterpret_cast<float2*>(smem + KG * 2 * BUF);             // [nb][gn_C] {scale, shift}
+  float* s_stat = reinterpret_cast<float*>(smem + KG * 2 * BUF + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0));  // [nb][32][2]
   const int b0 = (int)(m0 / HW);
   int pbl[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) pbl[i] = (int)(pbase[i] / HW) - b0;
   if (p.stat_out) {
-    for (int i = tid; i < CONV_MAX_NB * 64; i += 256) s_stat[i] = 0.f;
+    for (int i = threadIdx.x; i < CONV_MAX_NB * 64; i += NTHR) s_stat[i] = 0.f;
   }
   __syncthreads();
 
@@ -95,7 +105,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
 
   // Loads are unconditional (clamped address, then a select): a branch around each load makes
   // hipcc wait for every load separately - one L2 round trip per row instead of one per k-step.
-  auto load_regs = [&](auto SET, int kidx) __attribute__((always_inline)) {
+  auto load_regs = [&](auto SET, int kidx, bool adv) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
     const void* sg_src = SEG_FIELD(p, ks, src);
     const int sg_C = SEG_FIELD(p, ks, C), sg_coff = SEG_FIELD(p, ks, coff);
@@ -127,16 +137,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
       const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)32 * i * KC);
       if constexpr (S == 0) wreg0[i] = v; else wreg1[i] = v;
     }
-    const int nchunks = (sg_cin + KC - 1) / KC;
-    if (++kc == nchunks) {
-      kc = 0;
-      if (++ktap == sg_taps) { ktap = 0; ++ks; }
+    if (adv) {
+      const int nchunks = (sg_cin + KC - 1) / KC;
+      if (++kc == nchunks) {
+        kc = 0;
+        if (++ktap == sg_taps) { ktap = 0; ++ks; }
+      }
     }
   };
 
   auto write_lds = [&](auto SET, int buf) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    unsigned char* A = smem + buf * BUF;
+    unsigned char* A = gsm + buf * BUF;
     unsigned char* Wt = A + BM * 128;
 #pragma unroll
     for (int i = 0; i < AROWS; ++i) {
@@ -190,7 +202,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   const int fk = lane >> 4;
 
   auto compute = [&](int buf) __attribute__((always_inline)) {
-    const unsigned char* A = smem + buf * BUF;
+    const unsigned char* A = gsm + buf * BUF;
     const unsigned char* Wt = A + BM * 128;
     if constexpr (!F32) {
 #pragma unroll
@@ -260,7 +272,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     const int64_t mlast = min(M, m0 + BM) - 1;
     const int nb = (int)(mlast / HW) - b0 + 1;
     const int G = p.gn_G, C = p.gn_C;
-    for (int i = tid; i < nb * G; i += 256) {
+    for (int i = threadIdx.x; i < nb * G; i += NTHR) {
       const int bl = i / G, g = i - bl * G;
       double a0 = 0.0, a1 = 0.0;
       if (p.gn_nsplit < 0) {
@@ -284,7 +296,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     }
     __syncthreads();
     const int cpg = C / G;
-    for (int i = tid; i < nb * C; i += 256) {
+    for (int i = threadIdx.x; i < nb * C; i += NTHR) {
       const int bl = i / C, c = i - bl * C;
       const int g = c / cpg;
       const float sc = s_mr[2 * (bl * G + g) + 1] * p.gn_gamma[c];
@@ -298,30 +310,61 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
   //                 regs[(t+1)&1] (issued one iteration ago) -> LDS buf[(t+1)&1] ; barrier
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  if (nloc > 0) {
-    load_regs(S0{}, kbeg);
-    if (nloc > 1) load_regs(S1{}, kbeg + 1);
-    build_gn_table();            // its global reads overlap the first two k-steps' loads
-    __syncthreads();
-    write_lds(S0{}, 0);
-    __syncthreads();
-    int t = 0;
-    for (; t + 1 < nloc; t += 2) {
-      if (t + 2 < nloc) load_regs(S0{}, kbeg + t + 2);
-      compute(0);
-      write_lds(S1{}, 1);
-      __syncthreads();
-      if (t + 3 < nloc) load_regs(S1{}, kbeg + t + 3);
-      compute(1);
-      if (t + 2 < nloc) write_lds(S0{}, 0);
-      __syncthreads();
-    }
+  // every k-group executes the same number of barriers (gper steps); a group with fewer (or no)
+  // k-steps of its own just skips the work between them
+  // Loads are issued UNCONDITIONALLY every half-iteration (past the group's last k-step they
+  // re-read that last step, and nobody consumes them): with loads under a run-time condition the
+  // compiler cannot count what is in flight and waits vmcnt(0), which kills the 2-deep prefetch.
+  const int klast = max(kend - 1, 0);               // (a group without k-steps reads step 0 of the conv)
+  const int kfirst = min(kbeg, klast);
+  {   // cursor -> kfirst (it was advanced to kbeg, which may be one past the end for an idle group)
+    if (kbeg > klast && kbeg > 0) { ks = 0; ktap = 0; kc = 0; for (int i = 0; i < kfirst; ++i) {
+      const int nchunks = (SEG_FIELD(p, ks, cin) + KC - 1) / KC;
+      if (++kc == nchunks) { kc = 0; if (++ktap == SEG_FIELD(p, ks, taps)) { ktap = 0; ++ks; } } } }
+  }
+  load_regs(S0{}, kfirst, kfirst < klast);
+  load_regs(S1{}, min(kfirst + 1, klast), kfirst + 1 < klast);
+  build_gn_table();            // its global reads overlap the first two k-steps' loads
+  __syncthreads();
+  if (nloc > 0) write_lds(S0{}, 0);
+  __syncthreads();
+  for (int t = 0; t < gper; t += 2) {
+    load_regs(S0{}, min(kbeg + t + 2, klast), kbeg + t + 2 < klast);
     if (t < nloc) compute(0);
+    if (t + 1 < nloc) write_lds(S1{}, 1);
+    __syncthreads();
+    load_regs(S1{}, min(kbeg + t + 3, klast), kbeg + t + 3 < klast);
+    if (t + 1 < nloc) compute(1);
+    if (t + 2 < nloc) write_lds(S0{}, 0);
+    __syncthreads();
   }
 
-  // ---- epilogue --------------------------------------------------------------------------
+  // ---- sum the k-groups' accumulators through LDS (each group's own buffers, now idle) --------
+  if constexpr (KG > 1) {
+    f32x4* red = reinterpret_cast<f32x4*>(gsm);          // [NT*MT][256] f32x4 = 2*BUF bytes exactly
+    if (grp > 0) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) red[(j * MT + i) * 256 + tid] = acc[j][i];
+    }
+    __syncthreads();
+    if (grp == 0)                                         // group 0 owns the epilogue
+#pragma unroll
+    for (int g = 1; g < KG; ++g) {
+      const f32x4* rg = reinterpret_cast<const f32x4*>(smem + g * (2 * BUF));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) acc[j][i] += rg[(j * MT + i) * 256 + tid];
+    }
+  }
+
+  // ---- epilogue (k-group 0 only; the other groups just keep the barriers company) -----------
+  const bool owner = grp == 0;
   const int Cout = p.Cout;
   if (p.ksplit > 1) {
+    if (!owner) return;
     // raw fp32 partial sums -> slab [z][M][Cout]; fdbm's reduce kernel applies the epilogue
     float* slab = p.partial + (int64_t)blockIdx.z * M * Cout;
 #pragma unroll
@@ -353,7 +396,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + wn * WTN + j * 16 + fk * 4;
       float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-      const bool live = m < M && n < Cout;
+      const bool live = owner && m < M && n < Cout;
       if (live) conv_epilogue4<TO>(p, m, b, n, v);
       if (do_stat) {
         const float s1 = live ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
@@ -364,7 +407,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
         } else {
           // the 16 pixels of an m-tile lie in one image (H*W % 16 == 0)
           const float r1 = row16_sum(s1), r2 = row16_sum(s2);
-          if (frow == 0 && mt0 < M && n < Cout) {
+          if (owner && frow == 0 && mt0 < M && n < Cout) {
             const int bl = (int)(mt0 / HW) - b0;
             atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2], r1);
             atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2 + 1], r2);
@@ -379,7 +422,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + wn * WTN + j * 16 + fk * 4;
       const float r1 = row16_sum(a1[j]), r2 = row16_sum(a2[j]);
-      if (frow == 0 && mw < M && n < Cout) {
+      if (owner && frow == 0 && mw < M && n < Cout) {
         const int bl = (int)(mw / HW) - b0;
         atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2], r1);
         atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2 + 1], r2);
@@ -392,6 +435,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvParams p) {
     const int nb = (int)(mlast / HW) - b0 + 1;
     const int g0 = n0 / scpg;
     const int ng = min(p.stat_G - g0, (BN + scpg - 1) / scpg);
+    if (owner)
     for (int i = tid; i < nb * ng * 2; i += 256) {
       const int k = i & 1, g = g0 + (i >> 1) % ng, bl = (i >> 1) / ng;
       // spread over stat_nsplit rows: hundreds of blocks adding into ONE row serialise at memory
@@ -450,12 +494,12 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParam
   }
 }
 
-template <typename T, typename TO, int BM, int BN, bool GNP>
+template <typename T, typename TO, int BM, int BN, bool GNP, int KG>
 static int launch_conv(const ConvParams& p, hipStream_t st) {
-  constexpr int SMEM = 2 * (BM + BN) * 128 + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0) + CONV_MAX_NB * 64 * 4 * 2;
+  constexpr int SMEM = KG * 2 * (BM + BN) * 128 + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0) + CONV_MAX_NB * 64 * 4 * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, TO, BM, BN, GNP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, TO, BM, BN, GNP, KG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) {
       fdbm_set_error("fdbm_conv_igemm: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -465,7 +509,7 @@ static int launch_conv(const ConvParams& p, hipStream_t st) {
   }
   const int64_t M = (int64_t)p.B * p.H * p.W;
   dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)((p.Cout + BN - 1) / BN), (unsigned)p.ksplit);
-  conv_igemm_kernel<T, TO, BM, BN, GNP><<<grid, 256, SMEM, st>>>(p);
+  conv_igemm_kernel<T, TO, BM, BN, GNP, KG><<<grid, 256 * KG, SMEM, st>>>(p);
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm");
   if (p.ksplit > 1) {
     const int total = p.H * p.W * (p.Cout / 4);
@@ -477,23 +521,32 @@ static int launch_conv(const ConvParams& p, hipStream_t st) {
   return 0;
 }
 
+template <typename T, typename TO, bool GNP>
+static int launch_conv_gnp(const ConvParams& p, int bm, int bn, int kg, hipStream_t st) {
+  if (kg == 4) return launch_conv<T, TO, 64, 64, GNP, 4>(p, st);            // only the 64 x 64 tile has 4 k-groups
+  if (bm == 128 && bn == 128) return launch_conv<T, TO, 128, 128, GNP, 1>(p, st);
+  if (bm == 128 && bn == 64) return launch_conv<T, TO, 128, 64, GNP, 1>(p, st);
+  if (bm == 64 && bn == 128) return launch_conv<T, TO, 64, 128, GNP, 1>(p, st);
+  return launch_conv<T, TO, 64, 64, GNP, 1>(p, st);
+}
+
 template <typename T, typename TO>
-static int launch_conv_tile(const ConvParams& p, int bm, int bn, hipStream_t st) {
-  if (p.gn_sums) {            // GN prologue: only the small-M configurations are built
-    if (bm == 128 && bn == 128) return launch_conv<T, TO, 128, 128, true>(p, st);
-    if (bn == 128) return launch_conv<T, TO, 64, 128, true>(p, st);
-    return launch_conv<T, TO, 64, 64, true>(p, st);
-  }
-  if (bm == 128 && bn == 128) return launch_conv<T, TO, 128, 128, false>(p, st);
-  if (bm == 128 && bn == 64) return launch_conv<T, TO, 128, 64, false>(p, st);
-  if (bm == 64 && bn == 128) return launch_conv<T, TO, 64, 128, false>(p, st);
-  return launch_conv<T, TO, 64, 64, false>(p, st);
+static int launch_conv_tile(const ConvParams& p, int bm, int bn, int kg, hipStream_t st) {
+  return p.gn_sums ? launch_conv_gnp<T, TO, true>(p, bm, bn, kg, st) : launch_conv_gnp<T, TO, false>(p, bm, bn, kg, st);
 }
 
 extern "C" int fdbm_conv_kc(int dtype) { return dtype == FDBM_BF16 ? 64 : 32; }
 
 // Tile / split-K plan for a conv of M pixels, Cout channels, nk k-steps (host side, also used
 // by the caller to size the split-K workspace): fills bm, bn, ksplit.
+// k-groups inside the workgroup (see conv_igemm_kernel): 4 for the 64 x 64 tile when the layer has
+// too few tiles to give every CU two workgroups and enough k-steps to share out.
+static int plan_kgroups(int64_t nblocks, int bm, int bn, int nk) {
+  static const char* off = getenv("FDBM_CONV_KG");           // experiments: "1" disables
+  if (off && off[0] == '1') return 1;
+  return (bm == 64 && bn == 64 && nblocks <= 256 && nk >= 8) ? 4 : 1;
+}
+
 extern "C" int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int* ksplit) {
   const int target = 512;                         // blocks wanted in flight (2 per CU)
   int BMs = 128, BNs = Cout <= 64 ? 64 : 128;
@@ -502,9 +555,10 @@ extern "C" int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int
   if (blocks(BMs, BNs) < target) BMs = 64;
   int ks = 1;
   const int64_t nb = blocks(BMs, BNs);
-  if (nb < 256 && nk >= 4) {
-    ks = (int)(target / nb);
-    if (ks > nk / 2) ks = nk / 2;
+  const int kg = plan_kgroups(nb, BMs, BNs, nk);
+  if (nb * kg < 256 && nk >= 4 * kg) {
+    ks = (int)(target / (nb * kg));
+    if (ks > nk / (2 * kg)) ks = nk / (2 * kg);
     // keep the fp32 slabs small: ks * M * Cout * 4 bytes <= 8 MiB
     const int64_t per = M * Cout * 4;
     while (ks > 1 && ks * per > (8 << 20)) --ks;
@@ -606,7 +660,8 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   if (kind == 1) return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
-  if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_BF16) return launch_conv_tile<bf16_t, bf16_t>(p, bm, bn, st);
-  if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_F32) return launch_conv_tile<bf16_t, float>(p, bm, bn, st);
-  return launch_conv_tile<float, float>(p, bm, bn, st);
+  const int kg = plan_kgroups(((M + bm - 1) / bm) * ((a->Cout + bn - 1) / bn), bm, bn, nk);
+  if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_BF16) return launch_conv_tile<bf16_t, bf16_t>(p, bm, bn, kg, st);
+  if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_F32) return launch_conv_tile<bf16_t, float>(p, bm, bn, kg, st);
+  return launch_conv_tile<float, float>(p, bm, bn, kg, st);
 }

@@ -37,6 +37,23 @@ def run(B, H, W, cin, cout, taps=9, reps=30, gn=False):
     pl = hip.conv_plan_ex(B, H, W, cout, nk, taps)
     fl = 2.0 * B * H * W * cout * cin * taps
     print(f"B{B} {H}x{W} {cin}->{cout} nk={nk} gn={int(gn)} plan={pl} : {best*1e3:7.1f} us  {fl/best/1e9:7.1f} TFLOP/s", flush=True)
+if len(sys.argv) > 1 and sys.argv[1] == "floor":
+    run(1, 16, 16, 64, 64, taps=1)
+    run(1, 16, 16, 256, 256, taps=1)
+    run(1, 16, 16, 256, 256, taps=9)
+    run(1, 64, 64, 256, 256, taps=9)
+    run(1, 64, 64, 64, 64, taps=1)
+    sys.exit(0)
+if len(sys.argv) > 1 and sys.argv[1] == "mid":
+    for gn in (False, True):
+        run(1, 64, 64, 256, 256, gn=gn)
+        run(1, 64, 64, 512, 256, gn=gn)
+        run(1, 32, 32, 256, 256, gn=gn)
+        run(1, 32, 32, 512, 256, gn=gn)
+        run(1, 16, 16, 256, 256, gn=gn)
+        run(1, 128, 128, 128, 128, gn=gn)
+        run(1, 128, 128, 256, 128, gn=gn)
+    sys.exit(0)
 for gn in (False, True):
     run(1, 256, 256, 128, 128, gn=gn)
     run(1, 256, 256, 256, 128, gn=gn)

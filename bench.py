@@ -254,7 +254,7 @@ def main():
     result["roofline"] = {
         "bound": "mfma", "kernel": "conv_patch_kernel" if any(k == 1 for k in kinds) else "conv_igemm_kernel",
         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
-        "launches_per_forward": len(sel), "avg_launch_us": 1e3 * t_dom / len(sel) * 1e0,
+        "launches_per_forward": len(sel), "avg_launch_us": 1e6 * t_dom / len(sel),
         "algorithmic_gflop_per_launch_avg": f_dom / len(sel) / 1e9,
         "share_of_forward_flops": f_dom / sum(flops),
         "all_conv": {"achieved": sum(flops) / t_conv / 1e12, "frac": sum(flops) / t_conv / 1e12 / peak,

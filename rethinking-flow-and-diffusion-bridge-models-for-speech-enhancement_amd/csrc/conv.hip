@@ -540,10 +540,12 @@ extern "C" int fdbm_conv_kc(int dtype) { return dtype == FDBM_BF16 ? 64 : 32; }
 // Tile / split-K plan for a conv of M pixels, Cout channels, nk k-steps (host side, also used
 // by the caller to size the split-K workspace): fills bm, bn, ksplit.
 // k-groups inside the workgroup (see conv_igemm_kernel): 4 for the 64 x 64 tile when the layer has
-// too few tiles to give every CU two workgroups and enough k-steps to share out.
+// too few tiles to give every CU two workgroups and enough k-steps to share out (opt-in).
 static int plan_kgroups(int64_t nblocks, int bm, int bn, int nk) {
-  static const char* off = getenv("FDBM_CONV_KG");           // experiments: "1" disables
-  if (off && off[0] == '1') return 1;
+  // Measured on MI355X (B=1, ncsnpp_v2): 1.3-1.6x on isolated 64x64 / 32x32-map layers but a net
+  // loss inside the whole forward (RTF 27.7 vs 30.1), so it is opt-in: FDBM_CONV_KG=4.
+  static const char* on = getenv("FDBM_CONV_KG");
+  if (!(on && on[0] == '4')) return 1;
   return (bm == 64 && bn == 64 && nblocks <= 256 && nk >= 8) ? 4 : 1;
 }
 

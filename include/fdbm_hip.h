@@ -183,6 +183,11 @@ typedef struct {
   float* stat_out;
   int32_t stat_G;
   int32_t stat_nsplit;
+  /* optional: the same packed weights in MFMA-fragment-major order
+   * [kstep][CoutPad/16][8 chunks][16 rows][16 bytes] (row r, chunk c of `w` moves to
+   * [r/16][c][r%16]); the wave-per-tap kernel (plan kind 2) loads its operand fragments straight
+   * from it with 1 KiB-contiguous wave loads.  NULL: kind 2 is never selected. */
+  const void* w_frag;
 } fdbm_conv_args;
 
 int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream);
@@ -192,9 +197,15 @@ int fdbm_conv_kc(int dtype);
  * (the caller sizes `workspace` as ksplit * M * Cout * 4 bytes when ksplit > 1) */
 int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int* ksplit);
 /* full plan: kind 1 = halo-patch 3x3 kernel (tile th x 16 pixels, always inside one image),
- * kind 0 = tap-outer implicit GEMM with the (bm, bn, ksplit) of fdbm_conv_plan */
+ * kind 2 = wave-per-tap 3x3 kernel for small grids (th = tile width 16|8|4, bn = 16 x n-tiles,
+ * tile inside one image, no workspace), kind 0 = tap-outer implicit GEMM with the (bm, bn,
+ * ksplit) of fdbm_conv_plan */
 int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int first_taps, int* kind, int* th,
                       int* bm, int* bn, int* ksplit);
+/* kernel-selection policy used by fdbm_conv_plan_ex / fdbm_conv_igemm: bit 0 allows kind 1, bit 1
+ * allows kind 2, bit 2 turns on k-groups inside the kind-0 kernel; mask < 0 only queries.
+ * Returns the previous mask (default 3).  Results are the same convolution under every policy. */
+int fdbm_conv_policy(int mask);
 
 /* Combine('sum'): out = conv1x1(4->C)(pyr) + h (layerspp.py:52-57; ncsnpp_v2.py:302-305).
  * pyr f32 [M][4], w f32 [C][4], bias f32 [C], h/out dtype [M][C]; out may alias h. */

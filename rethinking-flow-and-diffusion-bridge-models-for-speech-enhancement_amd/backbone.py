@@ -169,6 +169,17 @@ class HipNCSNpp:
     def dense_out_ptr(self, prog, mod_idx):
         return prog.dense_out.data_ptr() + 4 * self.dense_off[mod_idx]
 
+    def frag_weight(self, wpack):
+        """Fragment-major copy of a packed conv weight (for the wave-per-tap kernel), made on first
+        use and shared by every program of this network."""
+        from .program import frag_major
+        if not hasattr(self, "_frag"):
+            self._frag = {}
+        key = wpack.data_ptr()
+        if key not in self._frag:
+            self._frag[key] = frag_major(wpack)
+        return self._frag[key]
+
     # ---- programs ------------------------------------------------------------------------
     def program(self, B, F, T):
         key = (B, F, T)

@@ -267,42 +267,12 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
   };
 
   auto build_gn_table = [&]() __attribute__((always_inline)) {
-  if constexpr (GNP) {
-    float* s_mr = s_stat + CONV_MAX_NB * 64;                                  // [nb][32][2] mean, rstd
-    const int64_t mlast = min(M, m0 + BM) - 1;
-    const int nb = (int)(mlast / HW) - b0 + 1;
-    const int G = p.gn_G, C = p.gn_C;
-    for (int i = threadIdx.x; i < nb * G; i += NTHR) {
-      const int bl = i / G, g = i - bl * G;
-      double a0 = 0.0, a1 = 0.0;
-      if (p.gn_nsplit < 0) {
-        const double* sd = reinterpret_cast<const double*>(p.gn_sums);
-        for (int sp = 0; sp < -p.gn_nsplit; ++sp) {
-          const double* q = sd + ((((int64_t)(b0 + bl)) * (-p.gn_nsplit) + sp) * G + g) * 2;
-          a0 += q[0];
-          a1 += q[1];
-        }
-      } else
-      for (int sp = 0; sp < p.gn_nsplit; ++sp) {
-        const float* q = p.gn_sums + ((((int64_t)(b0 + bl)) * p.gn_nsplit + sp) * G + g) * 2;
-        a0 += (double)q[0];
-        a1 += (double)q[1];
-      }
-      const double mean = a0 * p.gn_inv_count;
-      double var = a1 * p.gn_inv_count - mean * mean;
-      if (var < 0.0) var = 0.0;
-      s_mr[2 * i] = (float)mean;
-      s_mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+    if constexpr (GNP) {
+      const int64_t mlast = min(M, m0 + BM) - 1;
+      const int nb = (int)(mlast / HW) - b0 + 1;
+      // (scratch: the LDS tile buffers, not written before the barrier that follows)
+      conv_gn_table<NTHR>(p, b0, nb, s_gn, s_stat + CONV_MAX_NB * 64, smem);
     }
-    __syncthreads();
-    const int cpg = C / G;
-    for (int i = threadIdx.x; i < nb * C; i += NTHR) {
-      const int bl = i / C, c = i - bl * C;
-      const int g = c / cpg;
-      const float sc = s_mr[2 * (bl * G + g) + 1] * p.gn_gamma[c];
-      s_gn[i] = float2{sc, p.gn_beta[c] - s_mr[2 * (bl * G + g)] * sc};
-    }
-  }
   };
 
   // ---- main loop: loads run two k-steps ahead of the MFMAs ------------------------------
@@ -541,12 +511,33 @@ extern "C" int fdbm_conv_kc(int dtype) { return dtype == FDBM_BF16 ? 64 : 32; }
 // by the caller to size the split-K workspace): fills bm, bn, ksplit.
 // k-groups inside the workgroup (see conv_igemm_kernel): 4 for the 64 x 64 tile when the layer has
 // too few tiles to give every CU two workgroups and enough k-steps to share out (opt-in).
+// Kernel-selection policy: bit 0 = halo-patch kernel allowed, bit 1 = wave-per-tap kernel allowed,
+// bit 2 = k-groups in the tap-outer kernel.  Default 3, or from the environment (experiments):
+// FDBM_CONV_PATCH=0, FDBM_CONV_TAP=0 clear a bit, FDBM_CONV_KG=4 sets bit 2.
+static int g_policy = -1;
+static int conv_policy() {
+  if (g_policy < 0) {
+    int m = 3;
+    const char* e;
+    if ((e = getenv("FDBM_CONV_PATCH")) && e[0] == '0') m &= ~1;
+    if ((e = getenv("FDBM_CONV_TAP")) && e[0] == '0') m &= ~2;
+    if ((e = getenv("FDBM_CONV_KG")) && e[0] == '4') m |= 4;
+    g_policy = m;
+  }
+  return g_policy;
+}
+extern "C" int fdbm_conv_policy(int mask) {
+  const int old = conv_policy();
+  if (mask >= 0) g_policy = mask & 7;
+  return old;
+}
+
 static int plan_kgroups(int64_t nblocks, int bm, int bn, int nk) {
-  // Measured on MI355X (B=1, ncsnpp_v2): 1.3-1.6x on isolated 64x64 / 32x32-map layers but a net
-  // loss inside the whole forward (RTF 27.7 vs 30.1), so it is opt-in: FDBM_CONV_KG=4.
-  static const char* on = getenv("FDBM_CONV_KG");
-  if (!(on && on[0] == '4')) return 1;
-  return (bm == 64 && bn == 64 && nblocks <= 256 && nk >= 8) ? 4 : 1;
+  // Measured on MI355X (B=1, ncsnpp_v2): 1.3-1.6x on isolated 64x64-map layers, but opt-in (bit 2):
+  // the wave-per-tap kernel covers those layers by default.
+  if (!(conv_policy() & 4)) return 1;
+  // only where the tiles alone already cover half the CUs: below that split-K over MORE workgroups wins
+  return (bm == 64 && bn == 64 && nblocks >= 128 && nblocks <= 256 && nk >= 8) ? 4 : 1;
 }
 
 extern "C" int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int* ksplit) {
@@ -571,25 +562,46 @@ extern "C" int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int
 }
 
 int fdbm_launch_conv_patch(const ConvParams& p, int dt_in, int dt_out, int th, hipStream_t st);   // conv_patch.hip
+int fdbm_launch_conv_tap(const ConvParams& p, int dt_in, int dt_out, int tw, int nt, hipStream_t st);   // conv_tap.hip
 
 // Which kernel runs a conv of this shape: kind 1 = halo-patch 3x3 kernel (conv_patch.hip, tile
-// th x 16 pixels x 128 channels), kind 0 = tap-outer implicit GEMM (this file).
+// th x 16 pixels x 128 channels), kind 2 = wave-per-tap 3x3 kernel for small grids (conv_tap.hip,
+// tile 16 pixels x 1|4 m-tiles, th = tile width 16|8|4, bn = 16 x n-tiles), kind 0 = tap-outer
+// implicit GEMM (this file).
 extern "C" int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int first_taps, int* kind,
                                  int* th, int* bm, int* bn, int* ksplit) {
   const int64_t M = (int64_t)B * H * W;
   fdbm_conv_plan(M, Cout, nk, bm, bn, ksplit);
   *kind = 0;
   *th = 0;
-  static const char* force = getenv("FDBM_CONV_PATCH");     // experiments: "0" = never, unset = heuristic
-  if (force && force[0] == '0') return 0;
   const int64_t tiles16 = (int64_t)B * (H / 16) * (W / 16) * ((Cout + 127) / 128);
   // the halo-patch kernel wants >= 1 tile per CU (1-2 workgroups fit a CU); below that the
   // tap-outer kernel's smaller tiles fill the chip better
-  if (first_taps == 9 && H % 8 == 0 && W % 16 == 0 && *ksplit == 1 && 2 * tiles16 >= 256) {
+  static const char* pmin = getenv("FDBM_PATCH_MIN_TILES");  // experiments
+  const int64_t min_tiles = pmin ? atoi(pmin) : 128;
+  if ((conv_policy() & 1) && first_taps == 9 && H % 8 == 0 && W % 16 == 0 && *ksplit == 1 && tiles16 >= min_tiles) {
     *kind = 1;
     *th = (H % 16 == 0 && tiles16 >= 256) ? 16 : 8;
     static const char* fth = getenv("FDBM_PATCH_TH");          // experiments
     if (fth && fth[0] == '8') *th = 8;
+    return 0;
+  }
+  if (first_taps == 9 && (conv_policy() & 2)) {
+    int tw = 0, tr = 0;
+    if (W % 16 == 0 && H % 4 == 0) { tw = 16; tr = 4; }
+    else if (W % 8 == 0 && H % 8 == 0) { tw = 8; tr = 8; }
+    else if (W % 4 == 0 && H % 4 == 0) { tw = 4; tr = 4; }
+    if (tw) {
+      const int64_t tiles = (int64_t)B * (H / tr) * (W / tw);
+      auto grid = [&](int nt) { return tiles * ((Cout + 16 * nt - 1) / (16 * nt)); };
+      // latency-bound regime only: with more workgroups than that the weight fragments, which every
+      // workgroup reads from L2 by itself, cost more than the tap-outer kernel's shared LDS tile
+      static const char* tmax = getenv("FDBM_TAP_MAX_GRID");   // experiments
+      if (grid(4) <= (tmax ? atoi(tmax) : 1024)) {
+        const int nt = (Cout >= 64 && grid(4) >= 192) ? 4 : (Cout >= 32 && grid(2) >= 192) ? 2 : 1;
+        *kind = 2; *th = tw; *bm = 16; *bn = 16 * nt; *ksplit = 1;
+      }
+    }
   }
   return 0;
 }
@@ -627,7 +639,18 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   int bm, bn, ks, kind, th;
   const int64_t M = (int64_t)a->B * a->H * a->W;
   fdbm_conv_plan_ex(a->B, a->H, a->W, a->Cout, nk, a->seg[0].taps, &kind, &th, &bm, &bn, &ks);
-  if (kind == 1) bm = 16;          // a patch tile always lies inside one image
+  if (kind == 2) {                 // wave-per-tap kernel: 9-tap segments first, then 1-tap ones
+    bool seen1 = false, ordered = a->w_frag != nullptr;       // ... and fragment-major weights
+    for (int s = 0; s < a->nseg; ++s) {
+      if (a->seg[s].taps == 1) seen1 = true;
+      else if (seen1) ordered = false;
+    }
+    if (!ordered) {
+      kind = 0;
+      fdbm_conv_plan(M, a->Cout, nk, &bm, &bn, &ks);
+    }
+  }
+  if (kind != 0) bm = 16;          // a patch / tap tile always lies inside one image
   if (!a->workspace || a->workspace_bytes <= 0) ks = 1;
   while (ks > 1 && (int64_t)ks * M * a->Cout * 4 > a->workspace_bytes) --ks;
   p.ksplit = ks;
@@ -662,6 +685,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   if (kind == 1) return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
+  if (kind == 2) { p.ksplit = 1; p.w = a->w_frag; /* p.partial: unused (diagnostic stamps only) */ return fdbm_launch_conv_tap(p, a->dt_in, a->dt_out, th, bn / 16, st); }
   const int kg = plan_kgroups(((M + bm - 1) / bm) * ((a->Cout + bn - 1) / bn), bm, bn, nk);
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_BF16) return launch_conv_tile<bf16_t, bf16_t>(p, bm, bn, kg, st);
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_F32) return launch_conv_tile<bf16_t, float>(p, bm, bn, kg, st);

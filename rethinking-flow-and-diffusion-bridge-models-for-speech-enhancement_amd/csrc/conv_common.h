@@ -117,6 +117,70 @@ __device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int64_t m, i
   }
 }
 
+// GroupNorm prologue table: per (image of this workgroup, channel) {scale, shift} from the partial
+// (sum, sumsq) rows the producer left: s_gn[bl * gn_C + c] = {rstd * gamma, beta - mean * rstd * gamma}.
+// The |gn_nsplit| partial rows of an (image, group) are dealt out over NTHR / (32 nb) threads (a single
+// thread walking 16-64 rows one load after the other costs 5-20 us of pure latency), the partials are
+// summed in fp64 in a fixed order.  `scratch` is any LDS the kernel is not using yet
+// (>= NTHR * 16 bytes), s_mr holds [nb][32][2] floats.  Ends with a barrier.
+template <int NTHR>
+__device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int nb, float2* s_gn, float* s_mr,
+                                              unsigned char* scratch) {
+  const int tid = threadIdx.x;
+  const int G = p.gn_G, C = p.gn_C;
+  const int nslot = nb * 32;
+  const int nparts = NTHR / nslot;                 // >= 2 (nb <= 4, NTHR >= 256)
+  const int slot = tid % nslot, part = tid / nslot;
+  const int bl = slot >> 5, g = slot & 31;
+  double* red = reinterpret_cast<double*>(scratch);
+  const int nsp = p.gn_nsplit < 0 ? -p.gn_nsplit : p.gn_nsplit;
+  double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
+  if (g < G && part < nparts) {
+    if (p.gn_nsplit < 0) {
+      const double* sd = reinterpret_cast<const double*>(p.gn_sums) + (((int64_t)(b0 + bl)) * nsp * G + g) * 2;
+      int sp = part;
+      for (; sp + nparts < nsp; sp += 2 * nparts) {
+        const double* q = sd + (int64_t)sp * G * 2;
+        const double* r = sd + (int64_t)(sp + nparts) * G * 2;
+        a0 += q[0]; a1 += q[1]; c0 += r[0]; c1 += r[1];
+      }
+      if (sp < nsp) { const double* q = sd + (int64_t)sp * G * 2; a0 += q[0]; a1 += q[1]; }
+    } else {
+      const float* sf = p.gn_sums + (((int64_t)(b0 + bl)) * nsp * G + g) * 2;
+      int sp = part;
+      for (; sp + nparts < nsp; sp += 2 * nparts) {
+        const float* q = sf + (int64_t)sp * G * 2;
+        const float* r = sf + (int64_t)(sp + nparts) * G * 2;
+        a0 += (double)q[0]; a1 += (double)q[1]; c0 += (double)r[0]; c1 += (double)r[1];
+      }
+      if (sp < nsp) { const float* q = sf + (int64_t)sp * G * 2; a0 += (double)q[0]; a1 += (double)q[1]; }
+    }
+  }
+  if (part < nparts) {
+    red[(part * nslot + slot) * 2] = a0 + c0;
+    red[(part * nslot + slot) * 2 + 1] = a1 + c1;
+  }
+  __syncthreads();
+  if (tid < nslot && g < G) {
+    double t0 = 0.0, t1 = 0.0;
+    for (int q = 0; q < nparts; ++q) { t0 += red[(q * nslot + slot) * 2]; t1 += red[(q * nslot + slot) * 2 + 1]; }
+    const double mean = t0 * p.gn_inv_count;
+    double var = t1 * p.gn_inv_count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mr[2 * slot] = (float)mean;
+    s_mr[2 * slot + 1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int i = tid; i < nb * C; i += NTHR) {
+    const int ib = i / C, c = i - ib * C;
+    const int gg = c / cpg;
+    const float sc = s_mr[2 * (ib * 32 + gg) + 1] * p.gn_gamma[c];
+    s_gn[i] = float2{sc, p.gn_beta[c] - s_mr[2 * (ib * 32 + gg)] * sc};
+  }
+  __syncthreads();
+}
+
 // p.seg[ks] with a run-time ks makes the compiler copy the whole kernel argument to scratch
 // and index it there; chains of wave-uniform selects on constant indices stay in SGPRs.
 #define SEG_FIELD(p, ks, f) ((ks) == 0 ? (p).seg[0].f : (ks) == 1 ? (p).seg[1].f : (ks) == 2 ? (p).seg[2].f : (p).seg[3].f)

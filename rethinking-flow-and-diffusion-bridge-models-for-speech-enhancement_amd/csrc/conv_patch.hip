@@ -75,38 +75,9 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
     for (int i = tid; i < 64; i += NTHR) s_stat[i] = 0.f;
 
   auto build_gn_table = [&]() __attribute__((always_inline)) {
-    if constexpr (GNP) {
-      float* s_mr = s_stat + 64;
-      const int G = p.gn_G, C = p.gn_C;
-      for (int g = tid; g < G; g += NTHR) {
-        double a0 = 0.0, a1 = 0.0;
-        if (p.gn_nsplit < 0) {
-          const double* sd = reinterpret_cast<const double*>(p.gn_sums);
-          for (int sp = 0; sp < -p.gn_nsplit; ++sp) {
-            const double* q = sd + (((int64_t)b * (-p.gn_nsplit) + sp) * G + g) * 2;
-            a0 += q[0];
-            a1 += q[1];
-          }
-        } else
-        for (int sp = 0; sp < p.gn_nsplit; ++sp) {
-          const float* q = p.gn_sums + (((int64_t)b * p.gn_nsplit + sp) * G + g) * 2;
-          a0 += (double)q[0];
-          a1 += (double)q[1];
-        }
-        const double mean = a0 * p.gn_inv_count;
-        double var = a1 * p.gn_inv_count - mean * mean;
-        if (var < 0.0) var = 0.0;
-        s_mr[2 * g] = (float)mean;
-        s_mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
-      }
-      __syncthreads();
-      const int cpg = C / G;
-      for (int c = tid; c < C; c += NTHR) {
-        const int g = c / cpg;
-        const float sc = s_mr[2 * g + 1] * p.gn_gamma[c];
-        s_gn[c] = float2{sc, p.gn_beta[c] - s_mr[2 * g] * sc};
-      }
-    }
+    // (scratch: the second patch buffer, idle until the first chunk's taps; the first weight tile is
+    // being written to s_w meanwhile)
+    if constexpr (GNP) conv_gn_table<NTHR>(p, b, 1, s_gn, s_stat + 64, s_patch + PBUF);
   };
 
   // ---- chunk cursor -------------------------------------------------------------------------------

@@ -1,0 +1,458 @@
+// conv_tap.hip - 3x3 convolution for the small-batch, small-map layers: one wave per filter tap.
+//
+// At batch 1 the layers below the 256 x 256 level have too few output tiles to hide the serial
+// chain "load k-step -> LDS -> MFMA" of an output-stationary kernel: the tap-outer kernel
+// (conv.hip) spends 0.6-0.8 us per k-step on 36-72 k-steps with one workgroup per CU and needs a
+// second launch for its split-K slabs.  Here the taps of a 3x3 kernel run CONCURRENTLY:
+//   workgroup = 8 waves (2 per SIMD) = 16*MT pixels (one image) x 16*NT output channels
+//   wave w    = tap w (dy = w/3, dx = w%3): for every 128-byte input-channel chunk it multiplies
+//               the SAME halo patch in LDS (read at its own shift) with its own weight slice,
+//               whose MFMA fragments it loads straight from global memory (no LDS, no barrier:
+//               nobody else needs them);
+//   tap 8     = the "shared" tap: its (m-tile, k-half) products are dealt out over the 8 waves
+//               (wave w: m-tiles i with i%4 == w%4, k-half w/4) - any wave's accumulator will do;
+//   the 8 partial accumulators are summed through LDS at the end (3 barriers), and the
+//   epilogue (bias, time bias, residual, scale, Combine, output statistics) is spread over
+//   the waves by output tile.
+// The chain per workgroup is (#channel chunks) steps instead of 9 x that, every step carries
+// 9 x the loads in flight, the patch is staged once per chunk (GroupNorm + SiLU prologue costs
+// 1.4-2.3 x the tile instead of 9 x) and no slab / second launch is needed.
+// 1-tap segments (the res-block's 1x1 shortcut in the same accumulator) follow the 9-tap ones
+// and are handled like the shared tap (with the centre shift).
+// Tiles: TW = 16 | 8 | 4 pixels wide (16/TW image rows per 16-pixel MFMA m-tile), so that 8x8
+// and 4x4 maps are one tile.  Roofline: latency-bound by design (these layers hold < 1 us of
+// MFMA work per CU); it is selected only when the grid is small (fdbm_conv_plan_ex).
+#include "conv_common.h"
+
+#define TAP_NTHR 512
+
+// Diagnostic build only (-DFDBM_STAMPS, tools/tap_timeline.py): workgroup (0,0) writes shader-clock
+// stamps of its phases into the (otherwise unused) workspace.  The product library has none of it.
+#ifdef FDBM_STAMPS
+#define STAMP(i)                                                                                   \
+  do {                                                                                             \
+    if (p.partial && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                       \
+      reinterpret_cast<unsigned long long*>(p.partial)[i] = __builtin_amdgcn_s_memtime();          \
+  } while (0)
+#define STAMP_RT(i)                                                                                \
+  do {                                                                                             \
+    if (p.partial && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)                       \
+      reinterpret_cast<unsigned long long*>(p.partial)[i] = __builtin_amdgcn_s_memrealtime();      \
+  } while (0)
+#else
+#define STAMP(i)
+#define STAMP_RT(i)
+#endif
+
+template <typename T, typename TO, int TW, int MT, int NT, bool GNP>
+__global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, int tiles_x, int tiles_y) {
+  constexpr int KC = 128 / (int)sizeof(T);
+  constexpr int VW = 16 / (int)sizeof(T);
+  constexpr int RPM = 16 / TW;               // image rows per m-tile
+  constexpr int TR = MT * RPM;               // tile rows
+  constexpr int PCW = TW + 2;
+  constexpr int PROWS = (TR + 2) * PCW;
+  constexpr int PBUF = PROWS * 128;
+  constexpr int NPL = (PROWS * 8 + TAP_NTHR - 1) / TAP_NTHR;
+  constexpr int SLAB = MT * NT * 1024;       // one wave's accumulators: [MT*NT][64 lanes] f32x4
+  constexpr int MAIN = (2 * PBUF > 4 * SLAB) ? 2 * PBUF : 4 * SLAB;
+  constexpr bool F32 = sizeof(T) == 4;
+  static_assert(NPL <= 4, "patch staging assumes at most 4 items per thread");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_patch = smem;                                         // 2 x PBUF (slabs alias it later)
+  float2* s_gn = reinterpret_cast<float2*>(smem + MAIN);                 // [gn_C] {scale, shift}
+  float* s_stat = reinterpret_cast<float*>(smem + MAIN + (GNP ? CONV_GN_MAXC * 8 : 0));   // [32][2] + [32][2]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frow = lane & 15, fk = lane >> 4;
+  const int H = p.H, W = p.W;
+  const int tile = blockIdx.x;
+  const int tx = tile % tiles_x;
+  const int ty = (tile / tiles_x) % tiles_y;
+  const int b = tile / (tiles_x * tiles_y);
+  const int y0 = ty * TR, x0 = tx * TW;
+  const int n0 = blockIdx.y * (16 * NT);
+  const int64_t img = (int64_t)b * H * W;
+
+  // ---- per-thread patch items -------------------------------------------------------------------
+  int ppix[NPL], plds[NPL];
+  unsigned pmask = 0;
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int q = tid + TAP_NTHR * j;
+    const int prow = min(q >> 3, PROWS - 1), pch = q & 7;
+    const int pr = prow / PCW, pc = prow - pr * PCW;
+    const int iy = y0 + pr - 1, ix = x0 + pc - 1;
+    const bool ok = (q < PROWS * 8) && iy >= 0 && iy < H && ix >= 0 && ix < W;
+    ppix[j] = min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1);
+    plds[j] = (q < PROWS * 8) ? prow * 128 + ((pch ^ ((prow >> 1) & 7)) << 4) : -1;
+    pmask |= ok ? (1u << j) : 0u;
+  }
+  const int pchunk = tid & 7;          // 512 % 8 == 0: the 16-byte chunk is fixed per thread
+
+  // ---- this wave's activation rows in the patch: its own tap, and the centre tap -----------------
+  const int dy = wave / 3, dx = wave - dy * 3;
+  const int arow0 = (frow / TW + dy) * PCW + frow % TW + dx;     // m-tile i: + i * RPM * PCW
+  const int crow0 = (frow / TW + 1) * PCW + frow % TW + 1;       // centre tap (1-tap segments)
+  // (tap 8, the shared one, is PCW + 1 rows further: crow0 + PCW + 1)
+  constexpr int MROW = RPM * PCW;
+
+  if (p.stat_out)
+    for (int i = tid; i < 64; i += TAP_NTHR) s_stat[i] = 0.f;
+
+  auto build_gn_table = [&]() __attribute__((always_inline)) {
+    if constexpr (GNP) conv_gn_table<TAP_NTHR>(p, b, 1, s_gn, s_stat + 64, smem);   // (the patch buffers are still idle)
+  };
+
+  auto seg_nch = [&](int s) __attribute__((always_inline)) { return (SEG_FIELD(p, s, cin) + KC - 1) / KC; };
+
+  // ---- patch staging (as conv_patch.hip), two register sets: the patch of chunk c+2 is in flight
+  // while chunk c computes and chunk c+1's patch is transformed and written ----------------------------
+  uint4 pregA[NPL], pregB[NPL];
+  int pgcbA = -1, pgcbB = -1;
+  bool pcokA = true, pcokB = true;
+  auto load_patch = [&](auto SET, int s, int c) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    const void* sg_src = SEG_FIELD(p, s, src);
+    const int sg_C = SEG_FIELD(p, s, C), sg_coff = SEG_FIELD(p, s, coff), sg_cin = SEG_FIELD(p, s, cin);
+    const int cvalid = min(KC, sg_cin - c * KC);
+    const bool ok = pchunk * VW < cvalid;
+    const T* src = reinterpret_cast<const T*>(sg_src) + img * sg_C + sg_coff + (ok ? c * KC + pchunk * VW : 0);
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)ppix[j] * sg_C);
+      if constexpr (S == 0) pregA[j] = v; else pregB[j] = v;
+    }
+    int cb = -1;
+    if constexpr (GNP) {
+      const int sgn = s == 0 ? p.seg_gn[0] : s == 1 ? p.seg_gn[1] : s == 2 ? p.seg_gn[2] : p.seg_gn[3];
+      cb = sgn >= 0 ? sgn + c * KC + pchunk * VW : -1;
+    }
+    if constexpr (S == 0) { pcokA = ok; pgcbA = cb; } else { pcokB = ok; pgcbB = cb; }
+  };
+  // transform (GroupNorm scale/shift + SiLU) and store ONE patch item: issued between the MFMA groups of
+  // a chunk so that its VALU work runs beside them
+  auto write_patch_item = [&](auto SET, auto JJ, int buf) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    constexpr int j = decltype(JJ)::value;
+    if constexpr (j < NPL) {
+      unsigned char* P = s_patch + buf * PBUF;
+      const int pgcb = S == 0 ? pgcbA : pgcbB;
+      const bool pcok = S == 0 ? pcokA : pcokB;
+      uint4 v;
+      if constexpr (S == 0) v = pregA[j]; else v = pregB[j];
+      if constexpr (GNP) {
+        if (pgcb >= 0) {                   // wave-uniform: a property of the segment
+          const float2* tab = s_gn + pgcb;
+          if constexpr (!F32) {
+            bf16x8 e = *reinterpret_cast<bf16x8*>(&v);
+            if (p.gn_silu) {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { const float2 ss = tab[q]; e[q] = (bf16_t)silu_f((float)e[q] * ss.x + ss.y); }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { const float2 ss = tab[q]; e[q] = (bf16_t)((float)e[q] * ss.x + ss.y); }
+            }
+            v = *reinterpret_cast<uint4*>(&e);
+          } else {
+            f32x4 e = *reinterpret_cast<f32x4*>(&v);
+            if (p.gn_silu) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { const float2 ss = tab[q]; e[q] = silu_precise(e[q] * ss.x + ss.y); }
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) { const float2 ss = tab[q]; e[q] = e[q] * ss.x + ss.y; }
+            }
+            v = *reinterpret_cast<uint4*>(&e);
+          }
+        }
+      }
+      if (!(((pmask >> j) & 1u) && pcok)) v = uint4{0u, 0u, 0u, 0u};   // padding AFTER the activation
+      if (plds[j] >= 0) *reinterpret_cast<uint4*>(P + plds[j]) = v;
+    }
+  };
+  auto write_patch = [&](auto SET, int buf) __attribute__((always_inline)) {
+    write_patch_item(SET, std::integral_constant<int, 0>{}, buf);
+    write_patch_item(SET, std::integral_constant<int, 1>{}, buf);
+    write_patch_item(SET, std::integral_constant<int, 2>{}, buf);
+    write_patch_item(SET, std::integral_constant<int, 3>{}, buf);
+  };
+
+  // ---- weight fragments: straight from global memory into MFMA operand registers -------------------
+  // fragment-major weights [kidx][CoutPad/16][8 chunks][16 rows][16 B]: lane (frow, fk) of n-tile j,
+  // k-half kk reads (n-tile n0/16 + j, chunk 4 kk + fk, row frow) - the 64 lanes of a wave load
+  // 1 KiB contiguous (with row-major [CoutPad][128 B] weights consecutive lanes would sit 128 B apart
+  // and every lane would be its own memory transaction: measured 3.2 us per channel chunk).
+  // Two register sets (A: even chunks, B: odd chunks): a set is reloaded with the weights of chunk
+  // c+2 as soon as the MFMAs of chunk c have consumed it, so every load has a whole chunk of slack.
+  // w?0 / w?1: the two k-halves of this wave's tap; w?s: this wave's k-half of the shared tap
+  // (tap 8, or the only tap of a 1-tap segment).
+  uint4 wA0[NT], wA1[NT], wAs[NT], wB0[NT], wB1[NT], wBs[NT];
+  const int kkw = (wave >> 2) & 1;          // shared tap: this wave's k-half ...
+  const int miw = wave & 3;                 // ... and m-tiles i with (i & 3) == miw
+  auto w_ptr = [&](int s, int c, int kbase_s, bool shared) __attribute__((always_inline)) {
+    const int nch = seg_nch(s);
+    const int tap = SEG_FIELD(p, s, taps) == 9 ? (shared ? 8 : wave) : 0;
+    const int kidx = kbase_s + tap * nch + c;
+    return reinterpret_cast<const T*>(p.w) + ((int64_t)kidx * p.CoutPad + n0) * KC +
+           (((shared ? kkw * 4 : 0) + fk) * 16 + frow) * VW;
+  };
+
+  f32x4 acc[NT][MT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  auto mma = [&](const uint4& wf, const uint4& af, f32x4& c) __attribute__((always_inline)) {
+    if constexpr (!F32) {
+      Mfma<bf16_t>::run(wf, af, c);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        c = __builtin_amdgcn_mfma_f32_16x16x4f32(reinterpret_cast<const float*>(&wf)[q],
+                                                 reinterpret_cast<const float*>(&af)[q], c, 0, 0, 0);
+    }
+  };
+  auto a_frag = [&](const unsigned char* P, int row, int kk) __attribute__((always_inline)) {
+    const int cidx = kk * 4 + fk;
+    return *reinterpret_cast<const uint4*>(P + row * 128 + ((cidx ^ ((row >> 1) & 7)) << 4));
+  };
+
+  // ---- main loop over (segment, channel chunk) ----------------------------------------------------------
+  // chunk cursors: cur (computing), n1 (its patch is being written), n2 (being loaded); a cursor past
+  // the end stays on the last chunk (loads are unconditional, their results are never consumed)
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  int cs = 0, cc = 0, kbase = 0;
+  auto advance = [&](int& s_, int& c_, int& kb_) __attribute__((always_inline)) {   // -> false at the end
+    const int nch = seg_nch(s_);
+    if (c_ + 1 < nch) { ++c_; return true; }
+    if (s_ + 1 < p.nseg) { kb_ += SEG_FIELD(p, s_, taps) * nch; ++s_; c_ = 0; return true; }
+    return false;
+  };
+  auto load_w = [&](auto SET, int s_, int c_, int kb_) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    const T* wp = w_ptr(s_, c_, kb_, false);
+    const T* wq = w_ptr(s_, c_, kb_, true);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const uint4 v0 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
+      const uint4 v1 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
+      const uint4 vs = *reinterpret_cast<const uint4*>(wq + (int64_t)j * 16 * KC);
+      if constexpr (S == 0) { wA0[j] = v0; wA1[j] = v1; wAs[j] = vs; } else { wB0[j] = v0; wB1[j] = v1; wBs[j] = vs; }
+    }
+  };
+  int s1 = 0, c1 = 0, kb1 = 0;            // chunk 1 (or chunk 0 again when there is only one)
+  bool more = advance(s1, c1, kb1);
+  int s2 = s1, c2 = c1, kb2 = kb1;        // chunk 2
+  if (more) more = advance(s2, c2, kb2);
+  STAMP_RT(60);
+  STAMP(0);
+  load_patch(S0{}, 0, 0);
+  load_w(S0{}, 0, 0, 0);
+  load_patch(S1{}, s1, c1);
+  load_w(S1{}, s1, c1, kb1);
+  STAMP(1);
+  build_gn_table();
+  __syncthreads();
+  STAMP(2);
+  write_patch(S0{}, 0);
+  __syncthreads();
+  STAMP(3);
+  int nstamp = 4;
+  (void)nstamp;
+
+  // one chunk: SET = its parity.  LDS buffer SET holds its patch, register set SET its weights.
+  auto chunk = [&](auto SET) __attribute__((always_inline)) {
+    constexpr int S = decltype(SET)::value;
+    using OTHER = std::integral_constant<int, 1 - S>;
+    const int ntaps = SEG_FIELD(p, cs, taps);
+    load_patch(SET, s2, c2);              // patch of chunk c+2 -> this parity's registers (free since last barrier)
+    const unsigned char* P = s_patch + S * PBUF;
+    // weights of chunk c+2 are requested fragment by fragment right behind the MFMAs that consumed the
+    // register (the 64 B/clk vector-memory path is as busy as the matrix pipe here: they must overlap)
+    const T* wp = w_ptr(s2, c2, kb2, false);
+    const T* wq = w_ptr(s2, c2, kb2, true);
+    if (ntaps == 9) {
+      {
+        uint4 af[MT < 2 ? 2 : MT];         // (not [1]: one-element arrays end up in scratch memory)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) mma(S == 0 ? wA0[j] : wB0[j], af[i], acc[j][i]);
+          const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
+          if constexpr (S == 0) wA0[j] = v; else wB0[j] = v;
+        }
+      }
+      write_patch_item(OTHER{}, std::integral_constant<int, 0>{}, 1 - S);    // patch of chunk c+1, item 0
+      {
+        uint4 af[MT < 2 ? 2 : MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) mma(S == 0 ? wA1[j] : wB1[j], af[i], acc[j][i]);
+          const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
+          if constexpr (S == 0) wA1[j] = v; else wB1[j] = v;
+        }
+      }
+    } else {
+      write_patch_item(OTHER{}, std::integral_constant<int, 0>{}, 1 - S);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {        // (own-tap registers are not used by 1-tap chunks; keep them loaded)
+        const uint4 v0 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
+        if constexpr (S == 0) { wA0[j] = v0; wA1[j] = v1; } else { wB0[j] = v0; wB1[j] = v1; }
+      }
+    }
+    write_patch_item(OTHER{}, std::integral_constant<int, 1>{}, 1 - S);
+    {   // shared tap: tap 8 of a 9-tap chunk, or the only tap of a 1-tap chunk
+      const int srow0 = crow0 + (ntaps == 9 ? PCW + 1 : 0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if ((i & 3) == miw) {
+          const uint4 af = a_frag(P, srow0 + i * MROW, kkw);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma(S == 0 ? wAs[j] : wBs[j], af, acc[j][i]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const uint4 v = *reinterpret_cast<const uint4*>(wq + (int64_t)j * 16 * KC);
+        if constexpr (S == 0) wAs[j] = v; else wBs[j] = v;
+      }
+    }
+    STAMP(nstamp + 32);
+    write_patch_item(OTHER{}, std::integral_constant<int, 2>{}, 1 - S);
+    write_patch_item(OTHER{}, std::integral_constant<int, 3>{}, 1 - S);
+    __syncthreads();
+    STAMP(nstamp);
+    ++nstamp;
+    // cursors: cur <- n1 <- n2 <- n2 + 1
+    cs = s1; cc = c1; kbase = kb1;
+    s1 = s2; c1 = c2; kb1 = kb2;
+    if (more) more = advance(s2, c2, kb2);
+  };
+  int ntotal = 0;
+  for (int s_ = 0; s_ < p.nseg; ++s_) ntotal += seg_nch(s_);
+  for (int c = 0; c < ntotal; c += 2) {
+    chunk(S0{});
+    if (c + 1 < ntotal) chunk(S1{});
+  }
+  (void)cc; (void)kbase;
+
+  // ---- sum the 8 waves: 4..7 -> 0..3 through slabs, then slabs 0..3 are summed by output tile -------
+  f32x4* red = reinterpret_cast<f32x4*>(smem);
+  constexpr int SL4 = SLAB / 16;            // f32x4 per slab
+  if (wave >= 4) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) red[(wave - 4) * SL4 + (j * MT + i) * 64 + lane] = acc[j][i];
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[j][i] += red[wave * SL4 + (j * MT + i) * 64 + lane];
+  }
+  __syncthreads();
+  if (wave < 4) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) red[wave * SL4 + (j * MT + i) * 64 + lane] = acc[j][i];
+  }
+  __syncthreads();
+
+  STAMP(28);
+  // ---- epilogue, output tile t = j * MT + i handled by wave t mod 8 -----------------------------------------
+  const int Cout = p.Cout;
+  const bool do_stat = p.stat_out != nullptr;
+  const int scpg = do_stat ? Cout / p.stat_G : 1;
+  for (int t = wave; t < MT * NT; t += 8) {
+    const int j = t / MT, i = t - j * MT;
+    const f32x4 s = (red[t * 64 + lane] + red[SL4 + t * 64 + lane]) + (red[2 * SL4 + t * 64 + lane] + red[3 * SL4 + t * 64 + lane]);
+    const int y = y0 + i * RPM + frow / TW, x = x0 + frow % TW;
+    const int64_t m = img + (int64_t)y * W + x;
+    const int n = n0 + j * 16 + fk * 4;
+    float v[4] = {s[0], s[1], s[2], s[3]};
+    const bool live = n < Cout;
+    if (live) conv_epilogue4<TO>(p, m, b, n, v);
+    if (do_stat) {
+      const float s1 = live ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+      const float s2 = live ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.f;
+      const float r1 = row16_sum(s1), r2 = row16_sum(s2);
+      if (frow == 0 && live) {
+        atomicAdd(&s_stat[(n / scpg) * 2], r1);
+        atomicAdd(&s_stat[(n / scpg) * 2 + 1], r2);
+      }
+    }
+  }
+  STAMP(29);
+  STAMP_RT(61);
+  if (do_stat) {
+    __syncthreads();
+    const int g0 = n0 / scpg;
+    const int ng = min(p.stat_G - g0, (16 * NT + scpg - 1) / scpg);
+    for (int i = tid; i < ng * 2; i += TAP_NTHR) {
+      const int k = i & 1, g = g0 + (i >> 1);
+      atomicAdd(p.stat_out + (((int64_t)b * p.stat_nsplit + tile % p.stat_nsplit) * p.stat_G + g) * 2 + k,
+                s_stat[g * 2 + k]);
+    }
+  }
+}
+
+template <typename T, typename TO, int TW, int MT, int NT, bool GNP>
+static int launch_tap(const ConvParams& p, hipStream_t st) {
+  constexpr int RPM = 16 / TW, TR = MT * RPM;
+  constexpr int PBUF = (TR + 2) * (TW + 2) * 128;
+  constexpr int SLAB = MT * NT * 1024;
+  constexpr int MAIN = (2 * PBUF > 4 * SLAB) ? 2 * PBUF : 4 * SLAB;
+  constexpr int SMEM = MAIN + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 4 * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tap_kernel<T, TO, TW, MT, NT, GNP>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (e != hipSuccess) {
+      fdbm_set_error("fdbm_conv_igemm(tap): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return 2;
+    }
+    attr_set = true;
+  }
+  const int tiles_x = p.W / TW, tiles_y = p.H / TR;
+  dim3 grid((unsigned)(p.B * tiles_x * tiles_y), (unsigned)((p.Cout + 16 * NT - 1) / (16 * NT)));
+  conv_tap_kernel<T, TO, TW, MT, NT, GNP><<<grid, TAP_NTHR, SMEM, st>>>(p, tiles_x, tiles_y);
+  FDBM_LAUNCH_CHECK("fdbm_conv_igemm(tap)");
+  return 0;
+}
+
+template <typename T, typename TO, int TW, int MT>
+static int launch_tap_nt(const ConvParams& p, int nt, hipStream_t st) {
+  const bool gnp = p.gn_sums != nullptr;
+  if (nt == 4) return gnp ? launch_tap<T, TO, TW, MT, 4, true>(p, st) : launch_tap<T, TO, TW, MT, 4, false>(p, st);
+  if (nt == 2) return gnp ? launch_tap<T, TO, TW, MT, 2, true>(p, st) : launch_tap<T, TO, TW, MT, 2, false>(p, st);
+  return gnp ? launch_tap<T, TO, TW, MT, 1, true>(p, st) : launch_tap<T, TO, TW, MT, 1, false>(p, st);
+}
+
+template <typename T, typename TO>
+static int launch_tap_shape(const ConvParams& p, int tw, int nt, hipStream_t st) {
+  if (tw == 16) return launch_tap_nt<T, TO, 16, 4>(p, nt, st);
+  if (tw == 8) return launch_tap_nt<T, TO, 8, 4>(p, nt, st);
+  return launch_tap_nt<T, TO, 4, 1>(p, nt, st);
+}
+
+// called from fdbm_conv_igemm (conv.hip) with validated arguments; tw = tile width, nt = n-tiles
+int fdbm_launch_conv_tap(const ConvParams& p, int dt_in, int dt_out, int tw, int nt, hipStream_t st) {
+  if (dt_in == FDBM_BF16 && dt_out == FDBM_BF16) return launch_tap_shape<bf16_t, bf16_t>(p, tw, nt, st);
+  if (dt_in == FDBM_BF16 && dt_out == FDBM_F32) return launch_tap_shape<bf16_t, float>(p, tw, nt, st);
+  return launch_tap_shape<float, float>(p, tw, nt, st);
+}

@@ -11,7 +11,7 @@ import os
 import torch
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libfdbm_hip.so")
+LIB_PATH = os.environ.get("FDBM_HIP_LIB") or os.path.join(_CSRC, "libfdbm_hip.so")   # env: diagnostic builds
 
 F32, BF16 = 0, 1
 MAX_SEG = 4
@@ -39,7 +39,8 @@ class ConvArgs(ctypes.Structure):
                 ("gn_silu", ctypes.c_int32), ("gn_count", c_i64), ("gn_eps", c_float),
                 ("seg_gn_mask", ctypes.c_uint32),
                 ("comb_pyr", c_void_p), ("comb_w", c_void_p), ("comb_b", c_void_p),
-                ("stat_out", c_void_p), ("stat_G", ctypes.c_int32), ("stat_nsplit", ctypes.c_int32)]
+                ("stat_out", c_void_p), ("stat_G", ctypes.c_int32), ("stat_nsplit", ctypes.c_int32),
+                ("w_frag", c_void_p)]
 
 
 class Op(ctypes.Structure):
@@ -76,7 +77,7 @@ _SIGS = {
     "fdbm_run_program": [ctypes.POINTER(Op), c_int],
 }
 EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan",
-                                "fdbm_conv_plan_ex", "fdbm_ncsnpp_create", "fdbm_ncsnpp_destroy",
+                                "fdbm_conv_plan_ex", "fdbm_conv_policy", "fdbm_ncsnpp_create", "fdbm_ncsnpp_destroy",
                                 "fdbm_ncsnpp_forward"])
 
 
@@ -102,6 +103,8 @@ def lib():
         L.fdbm_conv_plan.restype = c_int
         L.fdbm_conv_plan_ex.argtypes = [c_int] * 6 + [ctypes.POINTER(c_int)] * 5
         L.fdbm_conv_plan_ex.restype = c_int
+        L.fdbm_conv_policy.argtypes = [c_int]
+        L.fdbm_conv_policy.restype = c_int
         L.fdbm_ncsnpp_create.argtypes = [ctypes.POINTER(Op), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int]
         L.fdbm_ncsnpp_create.restype = c_void_p
         L.fdbm_ncsnpp_destroy.argtypes = [c_void_p]
@@ -145,8 +148,13 @@ def conv_plan(M, cout, nk):
     return bm.value, bn.value, ks.value
 
 
+def conv_policy(mask=-1):
+    """Set (mask >= 0) / query the conv kernel-selection policy; returns the previous mask."""
+    return lib().fdbm_conv_policy(mask)
+
+
 def conv_plan_ex(B, H, W, cout, nk, first_taps):
-    """-> dict(kind, th, bm, bn, ksplit); kind 1 = halo-patch kernel."""
+    """-> dict(kind, th, bm, bn, ksplit); kind 1 = halo-patch kernel, 2 = wave-per-tap kernel (th = tile width, bn = 16 x n-tiles)."""
     v = [c_int() for _ in range(5)]
     lib().fdbm_conv_plan_ex(B, H, W, cout, nk, first_taps, *[ctypes.byref(x) for x in v])
     return dict(zip(("kind", "th", "bm", "bn", "ksplit"), [x.value for x in v]))

@@ -106,6 +106,13 @@ def pack_conv_weight(segments, kc, dtype, device):
     return out.contiguous(), cout_pad
 
 
+def frag_major(wpack):
+    """[nk, CoutPad, kc] row-major packed weights -> the fragment-major order the wave-per-tap kernel
+    reads: [nk][CoutPad/16][8 chunks][16 rows][16 bytes] (include/fdbm_hip.h, fdbm_conv_args.w_frag)."""
+    nk, cp, kc = wpack.shape
+    return wpack.view(nk, cp // 16, 16, 8, kc // 8).permute(0, 1, 3, 2, 4).contiguous()
+
+
 class Act:
     """An NHWC activation living in a pooled buffer."""
     __slots__ = ("t", "B", "H", "W", "C", "dtype", "stats")
@@ -252,16 +259,16 @@ class Program:
         image (always true for the halo-patch kernel) or cover at most 4 whole images
         (csrc/conv_common.h CONV_MAX_NB)."""
         pl = self.plan(a0, cout, segs)
-        if pl["kind"] == 1:
+        if pl["kind"] != 0:
             return True
         HW, bm = a0.H * a0.W, pl["bm"]
         return HW % 16 == 0 and (HW % bm == 0 or (bm % HW == 0 and bm // HW <= 4))
 
     def prologue_pays(self, a0, cout, segs):
-        """GroupNorm+SiLU inside the conv: cheap in the halo-patch kernel (1.3-1.4x the tensor),
-        9x redundant in the tap-outer kernel - there only where the layer is latency-bound."""
+        """GroupNorm+SiLU inside the conv: cheap in the halo-patch and wave-per-tap kernels (1.3-2.3x
+        the tensor), 9x redundant in the tap-outer kernel - there only where the layer is latency-bound."""
         pl = self.plan(a0, cout, segs)
-        if pl["kind"] == 1:
+        if pl["kind"] != 0:
             return True
         return segs[0][3] == 1 or a0.H * a0.W <= self.FUSE_PROLOGUE_MAX_HW
 
@@ -283,6 +290,8 @@ class Program:
             self.macs += a0.H * a0.W * cout * cin * taps
         ca.nseg = len(segs)
         ca.w = wpack.data_ptr()
+        if self.plan(a0, cout, segs)["kind"] == 2:
+            ca.w_frag = self.net.frag_weight(wpack).data_ptr()
         ca.bias = bias.data_ptr() if bias is not None else 0
         ca.tbias = tbias if tbias else 0
         ca.tbias_stride = tb_stride
@@ -308,12 +317,13 @@ class Program:
         if want_stats and self.fused and (cout // want_stats) % 4 == 0 and cout % want_stats == 0 \
                 and self.tile_ok(a0, cout, segs):
             pl = self.plan(a0, cout, segs)
-            tile_px = pl["th"] * 16 if pl["kind"] == 1 else pl["bm"]
+            tile_px = pl["th"] * 16 if pl["kind"] == 1 else 64 if pl["kind"] == 2 else pl["bm"]
             nsp = max(1, min(16, (HW // tile_px) // 8))      # rows the blocks' atomics are spread over
             slot = self.new_slot(nsp, want_stats)
             ca.stat_out, ca.stat_G, ca.stat_nsplit = slot, want_stats, nsp
             out.stats[want_stats] = (slot, nsp, HW * (cout // want_stats))
-        _, _, ks = hip.conv_plan(a0.M, cout, nk)
+        pl = self.plan(a0, cout, segs)
+        ks = pl["ksplit"] if pl["kind"] == 0 else 1
         if ks > 1:                      # split-K slabs: one shared scratch, ops run in order
             need = ks * a0.M * cout * 4
             if self.splitk_ws is None or self.splitk_ws.numel() < need:

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 import fdbm_amd  # noqa: F401
 from fdbm_amd import hip
-from fdbm_amd.program import pack_conv_weight
+from fdbm_amd.program import pack_conv_weight, frag_major
 from oracle import ncsnpp as onet
 
 pytestmark = pytest.mark.gpu
@@ -197,6 +197,9 @@ def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=No
         ca.seg[i].src, ca.seg[i].C, ca.seg[i].coff, ca.seg[i].cin, ca.seg[i].taps = d.data_ptr(), d.shape[3], 0, d.shape[3], taps
     ca.nseg = len(segs_nchw)
     ca.w = wpack.data_ptr()
+    wfrag = frag_major(wpack)                 # the wave-per-tap kernel's layout of the same weights
+    keep.append(wfrag)
+    ca.w_frag = wfrag.data_ptr()
     bd = bias.to(DEV) if bias is not None else None
     ca.bias = hip.ptr(bd)
     tb = tbias.to(DEV).contiguous() if tbias is not None else None
@@ -258,13 +261,26 @@ CONV_CASES = [
     ("patch_head", 1, 128, 128, [128], 4, 9, dict(head=True)),
     ("patch_c96", 1, 128, 128, [96], 192, 9, {}),
     ("mid_m_256", 1, 32, 32, [256], 256, 9, dict(res=True)),
+    ("tap_64_cat_short", 1, 64, 64, [256, 256], 256, 9, dict(shortcut=[256, 256], res=False)),   # wave-per-tap, 4 n-tiles
+    ("tap_32_b2", 2, 32, 32, [128], 64, 9, dict(res=True, tbias=True)),
+    ("tap_8x8_c96", 3, 8, 8, [96, 32], 96, 9, dict(shortcut=[96])),
+    ("tap_4x8", 2, 4, 8, [64], 32, 9, {}),
 ]
+
+
+@pytest.fixture(params=[3, 0], ids=["auto", "tapouter"])
+def conv_kernels(request):
+    """Every conv case runs under the default kernel selection (halo-patch / wave-per-tap / tap-outer by
+    shape) and with the tap-outer implicit GEMM forced."""
+    old = hip.conv_policy(request.param)
+    yield request.param
+    hip.conv_policy(old)
 
 
 @pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
-def test_conv_igemm(case, dtype, splitk):
+def test_conv_igemm(case, dtype, splitk, conv_kernels):
     name, B, H, W, cins, cout, taps, extra = case
     k = 3 if taps == 9 else 1
     xs = [rnd(B, c, H, W, seed=10 + i) for i, c in enumerate(cins)]
@@ -312,13 +328,15 @@ FUSED_CASES = [
     ("patch_gn", 1, 128, 128, [128], 128, 32, 32, False, False),
     ("patch_gn_cat", 2, 64, 128, [128, 64], 128, 32, 32, True, False),
     ("patch_gn_comb", 1, 128, 128, [64], 128, 16, 32, False, True),
+    ("tap_gn_64", 1, 64, 64, [256, 128], 256, 32, 32, True, False),
+    ("tap_gn_8_b2", 2, 8, 8, [128], 256, 32, 32, False, True),
 ]
 
 
 @pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
-def test_conv_fused_gn_combine_stats(case, dtype, splitk):
+def test_conv_fused_gn_combine_stats(case, dtype, splitk, conv_kernels):
     """conv3x3(silu(GroupNorm(cat(xs)))) [+ 1x1 shortcut of the raw input] [+ Combine] in one
     launch, plus the (sum, sumsq) of the stored output for the next GroupNorm."""
     name, B, H, W, cins, cout, G_in, G_out, shortcut, comb = case

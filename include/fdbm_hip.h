@@ -126,6 +126,13 @@ int fdbm_upfirdn2d(float* out, const float* in, const float* kernel, int major, 
 int fdbm_resample2x(void* out_plain, void* out_act, const void* in, const float* stats, int nsplit,
                     int64_t count, float eps, const float* gamma, const float* beta, int B, int H,
                     int W, int C, int G, int up, int dtype, void* stream);
+/* the same with UNIT statistics: stats rows hold G * stat_units (sum, sumsq) entries, stat_units
+ * consecutive ones per group - what a convolution's stat_out leaves with stat_G = C/4
+ * (stat_units = C/G/4); stat_units = 1 is fdbm_resample2x. */
+int fdbm_resample2x_units(void* out_plain, void* out_act, const void* in, const float* stats,
+                          int nsplit, int stat_units, int64_t count, float eps, const float* gamma,
+                          const float* beta, int B, int H, int W, int C, int G, int up, int dtype,
+                          void* stream);
 
 /* ------------------------------------------------------------------ convolution (implicit GEMM on MFMA)
  * nn.Conv2d 3x3 pad 1 / 1x1 (layers.py:100-105,118-124) and NIN (layers.py:546-555) as one
@@ -176,7 +183,7 @@ typedef struct {
   const float* comb_w;
   const float* comb_b;
   /* optional: accumulate (sum, sumsq) of the STORED output per (image, group of Cout/stat_G
-   * channels) into stat_out[B][stat_nsplit][stat_G][2] with atomics (caller zeroes it; a block
+   * channels) into stat_out[B][stat_nsplit][stat_G][2] (stat_G <= 64) with atomics (caller zeroes it; a block
    * adds into row blockIdx.x % stat_nsplit so the atomics do not all hit one address) - the
    * statistics the consuming GroupNorm needs, without another pass over the tensor; same layout
    * as fdbm_gn_stats' partial sums. */
@@ -188,6 +195,15 @@ typedef struct {
    * [r/16][c][r%16]); the wave-per-tap kernel (plan kind 2) loads its operand fragments straight
    * from it with 1 KiB-contiguous wave loads.  NULL: kind 2 is never selected. */
   const void* w_frag;
+  /* optional, instead of gn_sums: UNIT statistics of the GroupNorm input, one buffer per flagged
+   * segment s: gn_seg_sums[s] = float [B][gn_seg_nsplit[s]][cin_s/4][2], (sum, sumsq) over units of
+   * 4 channels - exactly what a convolution writing that tensor leaves in stat_out with
+   * stat_G = Cout/4.  Any GroupNorm whose group size is a multiple of 4 (all of NCSN++'s) is then
+   * normalised from its producers' epilogues, also across a channel concatenation whose group
+   * boundaries straddle the sources (e.g. 256 + 128 channels, 32 groups of 12).  The flagged
+   * segments must be segments 0 .. n-1 (seg_gn_mask = 2^n - 1). */
+  const float* gn_seg_sums[FDBM_MAX_SEG];
+  int32_t gn_seg_nsplit[FDBM_MAX_SEG];
 } fdbm_conv_args;
 
 int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream);

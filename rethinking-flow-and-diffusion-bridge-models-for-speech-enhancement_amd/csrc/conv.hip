@@ -379,8 +379,8 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
           const float r1 = row16_sum(s1), r2 = row16_sum(s2);
           if (owner && frow == 0 && mt0 < M && n < Cout) {
             const int bl = (int)(mt0 / HW) - b0;
-            atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2], r1);
-            atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2 + 1], r2);
+            atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2], r1);
+            atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2 + 1], r2);
           }
         }
       }
@@ -394,8 +394,8 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
       const float r1 = row16_sum(a1[j]), r2 = row16_sum(a2[j]);
       if (owner && frow == 0 && mw < M && n < Cout) {
         const int bl = (int)(mw / HW) - b0;
-        atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2], r1);
-        atomicAdd(&s_stat[(bl * 32 + n / scpg) * 2 + 1], r2);
+        atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2], r1);
+        atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2 + 1], r2);
       }
     }
   }
@@ -407,10 +407,10 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
     const int ng = min(p.stat_G - g0, (BN + scpg - 1) / scpg);
     if (owner)
     for (int i = tid; i < nb * ng * 2; i += 256) {
-      const int k = i & 1, g = g0 + (i >> 1) % ng, bl = (i >> 1) / ng;
+      const int k = i & 1, gl = (i >> 1) % ng, g = g0 + gl, bl = (i >> 1) / ng;
       // spread over stat_nsplit rows: hundreds of blocks adding into ONE row serialise at memory
       atomicAdd(p.stat_out + (((int64_t)(b0 + bl) * p.stat_nsplit + blockIdx.x % p.stat_nsplit) * p.stat_G + g) * 2 + k,
-                s_stat[(bl * 32 + g) * 2 + k]);
+                s_stat[(bl * 32 + gl) * 2 + k]);
     }
   }
 }
@@ -419,7 +419,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
 // output statistics of a block belong to one (image, group) row.
 template <typename TO>
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParams p) {
-  __shared__ float s_stat[64];
+  __shared__ float s_stat[128];          // up to 64 groups (Cout / 4 with Cout <= 256)
   const int Cout = p.Cout;
   const int HW = p.H * p.W;
   const int64_t M = (int64_t)p.B * HW;
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParam
   const bool do_stat = p.stat_out != nullptr;
   const int scpg = do_stat ? Cout / p.stat_G : 1;
   if (do_stat) {
-    if (threadIdx.x < 64) s_stat[threadIdx.x] = 0.f;
+    if (threadIdx.x < 128) s_stat[threadIdx.x] = 0.f;
     __syncthreads();
   }
   const int total = HW * nv;
@@ -657,9 +657,11 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   p.partial = reinterpret_cast<float*>(a->workspace);
   const int HW = a->H * a->W;
   for (int s = 0; s < FDBM_MAX_SEG; ++s) p.seg_gn[s] = -1;
-  if (a->gn_sums) {
+  const bool gn_units = a->gn_seg_sums[0] != nullptr;
+  FDBM_CHECK(!(gn_units && a->gn_sums), "fdbm_conv_igemm: give gn_sums OR gn_seg_sums, not both");
+  if (a->gn_sums || gn_units) {
     FDBM_CHECK(a->gn_gamma && a->gn_beta && a->gn_G > 0 && a->gn_G <= 32 && a->gn_C > 0 && a->gn_C <= CONV_GN_MAXC &&
-               a->gn_C % a->gn_G == 0 && a->gn_nsplit != 0 && a->gn_count > 0,
+               a->gn_C % a->gn_G == 0 && (gn_units || a->gn_nsplit != 0) && a->gn_count > 0,
                "fdbm_conv_igemm: bad GroupNorm prologue arguments (G=%d C=%d nsplit=%d)", a->gn_G, a->gn_C, a->gn_nsplit);
     FDBM_CHECK(HW % 16 == 0 && (HW % bm == 0 || (bm % HW == 0 && bm / HW <= CONV_MAX_NB)),
                "fdbm_conv_igemm: GroupNorm prologue needs H*W (%d) to tile the %d-pixel M tile", HW, bm);
@@ -667,7 +669,25 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     for (int s = 0; s < a->nseg; ++s)
       if (a->seg_gn_mask & (1u << s)) { p.seg_gn[s] = coff; coff += a->seg[s].cin; }
     FDBM_CHECK(coff == a->gn_C, "fdbm_conv_igemm: GroupNorm channels %d != flagged segment channels %d", a->gn_C, coff);
-    p.gn_sums = a->gn_sums; p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta;
+    if (gn_units) {
+      FDBM_CHECK((a->seg_gn_mask & (a->seg_gn_mask + 1)) == 0, "fdbm_conv_igemm: unit statistics need the flagged segments to be 0 .. n-1");
+      FDBM_CHECK((a->gn_C / a->gn_G) % 4 == 0, "fdbm_conv_igemm: unit statistics need gn_C/gn_G (%d/%d) to be a multiple of 4",
+                 a->gn_C, a->gn_G);
+      int uoff = 0;
+      for (int s = 0; s < a->nseg; ++s) {
+        if (!(a->seg_gn_mask & (1u << s))) continue;
+        FDBM_CHECK(a->gn_seg_sums[s] && a->gn_seg_nsplit[s] >= 1 && a->seg[s].cin % 4 == 0,
+                   "fdbm_conv_igemm: segment %d needs unit statistics (pointer, nsplit >= 1, cin %% 4 == 0)", s);
+        p.gn_useg[s] = a->gn_seg_sums[s]; p.gn_unsp[s] = a->gn_seg_nsplit[s];
+        p.gn_uoff[s] = uoff; p.gn_ucnt[s] = a->seg[s].cin / 4;
+        uoff += a->seg[s].cin / 4;
+      }
+      p.gn_unit = 1;
+      p.gn_sums = a->gn_seg_sums[0];            // non-null = "prologue on" for the launchers
+    } else {
+      p.gn_sums = a->gn_sums;
+    }
+    p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta;
     p.gn_nsplit = a->gn_nsplit; p.gn_G = a->gn_G; p.gn_C = a->gn_C; p.gn_silu = a->gn_silu;
     p.gn_inv_count = 1.0 / (double)a->gn_count; p.gn_eps = a->gn_eps;
   }
@@ -676,7 +696,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     p.comb_pyr = a->comb_pyr; p.comb_w = a->comb_w; p.comb_b = a->comb_b;
   }
   if (a->stat_out) {
-    FDBM_CHECK(a->stat_G > 0 && a->stat_G <= 32 && a->Cout % a->stat_G == 0 && (a->Cout / a->stat_G) % 4 == 0,
+    FDBM_CHECK(a->stat_G > 0 && a->stat_G <= 64 && a->Cout % a->stat_G == 0 && (a->Cout / a->stat_G) % 4 == 0,
                "fdbm_conv_igemm: output statistics need Cout/G (%d/%d) to be a multiple of 4", a->Cout, a->stat_G);
     FDBM_CHECK(HW % 16 == 0 && (HW % bm == 0 || (bm % HW == 0 && bm / HW <= CONV_MAX_NB)),
                "fdbm_conv_igemm: output statistics need H*W (%d) to tile the %d-pixel M tile", HW, bm);

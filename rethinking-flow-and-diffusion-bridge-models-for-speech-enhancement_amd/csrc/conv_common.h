@@ -58,6 +58,12 @@ struct ConvParams {
   double gn_inv_count;
   float gn_eps;
   int seg_gn[FDBM_MAX_SEG];
+  // unit statistics (gn_unit != 0): per flagged segment s a buffer [B][gn_unsp[s]][gn_ucnt[s]][2] of
+  // (sum, sumsq) over units of 4 channels, as the convs' stat_out leaves them with stat_G = Cout/4;
+  // gn_uoff[s] = first unit of the segment inside the normalised (virtually concatenated) input
+  int gn_unit;
+  const float* gn_useg[FDBM_MAX_SEG];
+  int gn_unsp[FDBM_MAX_SEG], gn_uoff[FDBM_MAX_SEG], gn_ucnt[FDBM_MAX_SEG];
   // Combine('sum') folded into the epilogue: out += comb_b[n] + comb_w[n][0..3] . pyr[m][0..3]
   const float* comb_pyr;
   const float* comb_w;
@@ -135,7 +141,22 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
   double* red = reinterpret_cast<double*>(scratch);
   const int nsp = p.gn_nsplit < 0 ? -p.gn_nsplit : p.gn_nsplit;
   double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
-  if (g < G && part < nparts) {
+  if (g < G && part < nparts && p.gn_unit) {
+    // units of 4 channels, one buffer per segment: group g = units [g * upg, (g + 1) * upg)
+    const int upg = (C / G) >> 2;
+    for (int u = g * upg; u < (g + 1) * upg; ++u) {
+      const int sg = (p.seg_gn[1] >= 0 && u >= p.gn_uoff[1]) ? ((p.seg_gn[2] >= 0 && u >= p.gn_uoff[2]) ? ((p.seg_gn[3] >= 0 && u >= p.gn_uoff[3]) ? 3 : 2) : 1) : 0;
+      const float* base = sg == 0 ? p.gn_useg[0] : sg == 1 ? p.gn_useg[1] : sg == 2 ? p.gn_useg[2] : p.gn_useg[3];
+      const int usp = sg == 0 ? p.gn_unsp[0] : sg == 1 ? p.gn_unsp[1] : sg == 2 ? p.gn_unsp[2] : p.gn_unsp[3];
+      const int ucnt = sg == 0 ? p.gn_ucnt[0] : sg == 1 ? p.gn_ucnt[1] : sg == 2 ? p.gn_ucnt[2] : p.gn_ucnt[3];
+      const int uoff = sg == 0 ? p.gn_uoff[0] : sg == 1 ? p.gn_uoff[1] : sg == 2 ? p.gn_uoff[2] : p.gn_uoff[3];
+      const float* sf = base + (((int64_t)(b0 + bl)) * usp * ucnt + (u - uoff)) * 2;
+      for (int sp = part; sp < usp; sp += nparts) {
+        const float* q = sf + (int64_t)sp * ucnt * 2;
+        a0 += (double)q[0]; a1 += (double)q[1];
+      }
+    }
+  } else if (g < G && part < nparts) {
     if (p.gn_nsplit < 0) {
       const double* sd = reinterpret_cast<const double*>(p.gn_sums) + (((int64_t)(b0 + bl)) * nsp * G + g) * 2;
       int sp = part;

@@ -325,8 +325,8 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
       const int n = n0 + wn * 64 + j * 16 + fk * 4;
       const float r1 = row16_sum(a1[j]), r2 = row16_sum(a2[j]);
       if (frow == 0 && n < Cout) {
-        atomicAdd(&s_stat[(n / scpg) * 2], r1);
-        atomicAdd(&s_stat[(n / scpg) * 2 + 1], r2);
+        atomicAdd(&s_stat[((n - n0) / scpg) * 2], r1);
+        atomicAdd(&s_stat[((n - n0) / scpg) * 2 + 1], r2);
       }
     }
     __syncthreads();
@@ -335,7 +335,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
     for (int i = tid; i < ng * 2; i += NTHR) {
       const int k = i & 1, g = g0 + (i >> 1);
       atomicAdd(p.stat_out + (((int64_t)b * p.stat_nsplit + tile % p.stat_nsplit) * p.stat_G + g) * 2 + k,
-                s_stat[g * 2 + k]);
+                s_stat[(g - g0) * 2 + k]);
     }
   }
 }

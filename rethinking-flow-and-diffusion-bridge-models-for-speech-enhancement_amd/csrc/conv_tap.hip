@@ -392,8 +392,8 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
       const float s2 = live ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.f;
       const float r1 = row16_sum(s1), r2 = row16_sum(s2);
       if (frow == 0 && live) {
-        atomicAdd(&s_stat[(n / scpg) * 2], r1);
-        atomicAdd(&s_stat[(n / scpg) * 2 + 1], r2);
+        atomicAdd(&s_stat[((n - n0) / scpg) * 2], r1);
+        atomicAdd(&s_stat[((n - n0) / scpg) * 2 + 1], r2);
       }
     }
   }
@@ -406,7 +406,7 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
     for (int i = tid; i < ng * 2; i += TAP_NTHR) {
       const int k = i & 1, g = g0 + (i >> 1);
       atomicAdd(p.stat_out + (((int64_t)b * p.stat_nsplit + tile % p.stat_nsplit) * p.stat_G + g) * 2 + k,
-                s_stat[g * 2 + k]);
+                s_stat[(g - g0) * 2 + k]);
     }
   }
 }

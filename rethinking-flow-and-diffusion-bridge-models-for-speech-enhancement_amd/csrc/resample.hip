@@ -75,12 +75,12 @@ __global__ void __launch_bounds__(256) resample2x_kernel(
     T* __restrict__ out_plain, T* __restrict__ out_act, const T* __restrict__ in,
     const float* __restrict__ stats, int nsplit, double inv_count, float eps,
     const float* __restrict__ gamma, const float* __restrict__ beta,
-    int H, int W, int C, int G, int chunks) {
+    int H, int W, int C, int G, int chunks, int upg) {
   constexpr int VW = DT<T>::vecw;
   extern __shared__ float s_ss[];   // [2][C] scale / shift
   __shared__ double s_red[ACT ? 8 * 32 * 2 : 1];
   const int b = blockIdx.y;
-  if (ACT) gn_scale_shift(s_ss, s_red, stats, nsplit, inv_count, eps, b, C, G, gamma, beta);
+  if (ACT) gn_scale_shift(s_ss, s_red, stats, nsplit, inv_count, eps, b, C, G, gamma, beta, upg);
   const int OH = UP ? 2 * H : H / 2, OW = UP ? 2 * W : W / 2;
   const int nvec = C / VW;
   const int64_t total = (int64_t)OH * OW * nvec;
@@ -138,7 +138,16 @@ extern "C" int fdbm_resample2x(void* out_plain, void* out_act, const void* in, c
                                int nsplit, int64_t count, float eps,
                                const float* gamma, const float* beta, int B, int H, int W, int C,
                                int G, int up, int dtype, void* stream) {
+  return fdbm_resample2x_units(out_plain, out_act, in, stats, nsplit, 1, count, eps, gamma, beta, B, H, W, C, G, up,
+                               dtype, stream);
+}
+
+extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void* in, const float* stats,
+                                     int nsplit, int stat_units, int64_t count, float eps,
+                                     const float* gamma, const float* beta, int B, int H, int W, int C,
+                                     int G, int up, int dtype, void* stream) {
   FDBM_CHECK(in && (out_plain || out_act), "fdbm_resample2x: null pointer");
+  FDBM_CHECK(stat_units >= 1 && (stat_units == 1 || nsplit > 0), "fdbm_resample2x: unit statistics are float partial sums (nsplit > 0)");
   FDBM_CHECK((out_act != nullptr) == (stats != nullptr), "fdbm_resample2x: out_act needs GroupNorm statistics (and vice versa)");
   FDBM_CHECK(!out_act || (gamma && beta && G > 0 && G <= 32 && C % G == 0 && C <= 1024), "fdbm_resample2x: bad GroupNorm arguments");
   FDBM_CHECK(nsplit == 0 || count > 0, "fdbm_resample2x: bad nsplit/count");
@@ -154,7 +163,7 @@ extern "C" int fdbm_resample2x(void* out_plain, void* out_act, const void* in, c
   dim3 grid(chunks, B);
   const size_t smem = out_act ? 2 * (size_t)C * sizeof(float) : 0;
   hipStream_t st = (hipStream_t)stream;
-#define RS(TT, U, P, A) resample2x_kernel<TT, U, P, A><<<grid, 256, smem, st>>>((TT*)out_plain, (TT*)out_act, (const TT*)in, stats, nsplit, inv_count, eps, gamma, beta, H, W, C, G, chunks)
+#define RS(TT, U, P, A) resample2x_kernel<TT, U, P, A><<<grid, 256, smem, st>>>((TT*)out_plain, (TT*)out_act, (const TT*)in, stats, nsplit, inv_count, eps, gamma, beta, H, W, C, G, chunks, stat_units)
 #define RS_DISPATCH(TT)                                                         \
   do {                                                                          \
     const bool P_ = out_plain != nullptr, A_ = out_act != nullptr;              \

@@ -49,8 +49,8 @@ extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* stream) {
                            CFP(9), I(10), I(11), I(12), I(13), I(14), stream);
         break;
       case FDBM_OP_RESAMPLE:
-        rc = fdbm_resample2x(P(0), P(1), CP(2), CFP(3), I(4), o.iarg[5], o.farg[0], CFP(6), CFP(7),
-                             I(8), I(9), I(10), I(11), I(12), I(13), I(14), stream);
+        rc = fdbm_resample2x_units(P(0), P(1), CP(2), CFP(3), I(4), I(15) > 0 ? I(15) : 1, o.iarg[5], o.farg[0],
+                                   CFP(6), CFP(7), I(8), I(9), I(10), I(11), I(12), I(13), I(14), stream);
         break;
       case FDBM_OP_COMBINE:
         rc = fdbm_combine(P(0), CP(1), CFP(2), CFP(3), CFP(4), o.iarg[5], I(6), I(7), stream);

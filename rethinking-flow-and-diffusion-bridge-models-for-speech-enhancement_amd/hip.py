@@ -40,7 +40,8 @@ class ConvArgs(ctypes.Structure):
                 ("seg_gn_mask", ctypes.c_uint32),
                 ("comb_pyr", c_void_p), ("comb_w", c_void_p), ("comb_b", c_void_p),
                 ("stat_out", c_void_p), ("stat_G", ctypes.c_int32), ("stat_nsplit", ctypes.c_int32),
-                ("w_frag", c_void_p)]
+                ("w_frag", c_void_p),
+                ("gn_seg_sums", c_void_p * MAX_SEG), ("gn_seg_nsplit", ctypes.c_int32 * MAX_SEG)]
 
 
 class Op(ctypes.Structure):
@@ -66,6 +67,7 @@ _SIGS = {
     "fdbm_gn_apply": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_i64, c_float, c_void_p, c_void_p] + [c_int] * 5,
     "fdbm_upfirdn2d": [c_void_p] * 3 + [c_int] * 14,
     "fdbm_resample2x": [c_void_p] * 4 + [c_int, c_i64, c_float, c_void_p, c_void_p] + [c_int] * 7,
+    "fdbm_resample2x_units": [c_void_p] * 4 + [c_int, c_int, c_i64, c_float, c_void_p, c_void_p] + [c_int] * 7,
     "fdbm_conv_igemm": [ctypes.POINTER(ConvArgs)],
     "fdbm_combine": [c_void_p] * 5 + [c_i64, c_int, c_int],
     "fdbm_attention": [c_void_p, c_void_p] + [c_int] * 4,

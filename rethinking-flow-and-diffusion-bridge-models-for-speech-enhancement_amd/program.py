@@ -115,11 +115,13 @@ def frag_major(wpack):
 
 class Act:
     """An NHWC activation living in a pooled buffer."""
-    __slots__ = ("t", "B", "H", "W", "C", "dtype", "stats")
+    __slots__ = ("t", "B", "H", "W", "C", "dtype", "ustats")
 
     def __init__(self, t, B, H, W, C, dtype):
         self.t, self.B, self.H, self.W, self.C, self.dtype = t, B, H, W, C, dtype
-        self.stats = {}      # G -> (sums buffer, nsplit, count) produced by the conv that wrote it
+        # (slot pointer, nsplit): UNIT statistics [B][nsplit][C/4][2] left by the conv that wrote this
+        # tensor (fdbm_conv_args.stat_out with stat_G = C/4), or None
+        self.ustats = None
 
     @property
     def ptr(self):
@@ -206,16 +208,20 @@ class Program:
     def emit(self, opcode, iargs, fargs=()):
         self.ops.append((opcode, [int(v) for v in iargs], [float(v) for v in fargs]))
 
-    def stats_for(self, srcs, G):
-        """(sums buffer or slot pointer, nsplit, count, owned) of GroupNorm(G) over cat(srcs):
-        the producer's fused statistics when a single source carries them, else a stats pass."""
-        if len(srcs) == 1 and G in srcs[0].stats:
-            return srcs[0].stats[G], False
-        return self.gn_stats(srcs, G), True
+    def stats_for(self, srcs, G, units_ok=True):
+        """Statistics of GroupNorm(G) over cat(srcs) -> (descriptor, owned).  descriptor is
+        ("unit", [(ptr, nsplit, C_s), ...], count) when every source carries its producer's unit
+        statistics and the consumer can read them (conv prologues, resample), else
+        ("group", (buffer, nsplit, count)) from a statistics pass."""
+        C = sum(a.C for a in srcs)
+        if units_ok and self.fused and all(a.ustats is not None for a in srcs) and (C // G) % 4 == 0:
+            HW = srcs[0].H * srcs[0].W
+            return ("unit", [(a.ustats[0], a.ustats[1], a.C) for a in srcs], HW * (C // G)), False
+        return ("group", self.gn_stats(srcs, G)), True
 
     def release_stats(self, st, owned):
         if owned:
-            self.pool.put(st[0])
+            self.pool.put(st[1][0])
 
     def gn_stats(self, srcs, G):
         """srcs: list of 1 or 2 Acts (virtual concat) -> (partial sums buffer, nsplit, count);
@@ -236,7 +242,8 @@ class Program:
         a1 = srcs[1] if len(srcs) > 1 else None
         C = a0.C + (a1.C if a1 else 0)
         out = self.new_act(a0.H, a0.W, C)
-        partial, nsplit, count = st
+        assert st[0] == "group"
+        partial, nsplit, count = st[1]
         pptr = partial if isinstance(partial, int) else partial.data_ptr()
         self.emit(hip.OP_GN_APPLY, [out.ptr, a0.ptr, a0.C, a1.ptr if a1 else 0, a1.C if a1 else 0,
                                     pptr, nsplit, count, gamma.data_ptr(), beta.data_ptr(),
@@ -302,10 +309,20 @@ class Program:
         ca.dt_in = hip.dt_code(a0.dtype)
         ca.dt_out = hip.dt_code(out.dtype)
         if gn is not None:
-            (gbuf, gnsplit, gcount), gamma, beta, G, C, silu, nflag = gn
-            ca.gn_sums = gbuf if isinstance(gbuf, int) else gbuf.data_ptr()
+            st, gamma, beta, G, C, silu, nflag = gn
+            if st[0] == "unit":
+                _, per_seg, gcount = st
+                assert len(per_seg) == nflag
+                for i, (uptr, unsp, uc) in enumerate(per_seg):
+                    assert uc == segs[i][2]
+                    ca.gn_seg_sums[i], ca.gn_seg_nsplit[i] = uptr, unsp
+                ca.gn_nsplit = 0
+            else:
+                gbuf, gnsplit, gcount = st[1]
+                ca.gn_sums = gbuf if isinstance(gbuf, int) else gbuf.data_ptr()
+                ca.gn_nsplit = gnsplit
             ca.gn_gamma, ca.gn_beta = gamma.data_ptr(), beta.data_ptr()
-            ca.gn_nsplit, ca.gn_G, ca.gn_C, ca.gn_silu = gnsplit, G, C, 1 if silu else 0
+            ca.gn_G, ca.gn_C, ca.gn_silu = G, C, 1 if silu else 0
             ca.gn_count, ca.gn_eps = gcount, 1e-6
             ca.seg_gn_mask = (1 << nflag) - 1
         if comb is not None:
@@ -314,14 +331,13 @@ class Program:
         kc = hip.conv_kc(ca.dt_in)
         nk = sum(taps * ((cin + kc - 1) // kc) for (_, _, cin, taps) in segs)
         HW = a0.H * a0.W
-        if want_stats and self.fused and (cout // want_stats) % 4 == 0 and cout % want_stats == 0 \
-                and self.tile_ok(a0, cout, segs):
+        if want_stats and self.fused and cout % 4 == 0 and cout // 4 <= 64 and self.tile_ok(a0, cout, segs):
             pl = self.plan(a0, cout, segs)
             tile_px = pl["th"] * 16 if pl["kind"] == 1 else 64 if pl["kind"] == 2 else pl["bm"]
             nsp = max(1, min(16, (HW // tile_px) // 8))      # rows the blocks' atomics are spread over
-            slot = self.new_slot(nsp, want_stats)
-            ca.stat_out, ca.stat_G, ca.stat_nsplit = slot, want_stats, nsp
-            out.stats[want_stats] = (slot, nsp, HW * (cout // want_stats))
+            slot = self.new_slot(nsp, cout // 4)             # unit statistics: any later GroupNorm can use them
+            ca.stat_out, ca.stat_G, ca.stat_nsplit = slot, cout // 4, nsp
+            out.ustats = (slot, nsp)
         pl = self.plan(a0, cout, segs)
         ks = pl["ksplit"] if pl["kind"] == 0 else 1
         if ks > 1:                      # split-K slabs: one shared scratch, ops run in order
@@ -338,13 +354,21 @@ class Program:
         OH, OW = (2 * a.H, 2 * a.W) if up else (a.H // 2, a.W // 2)
         plain = self.new_act(OH, OW, a.C, a.dtype) if want_plain else None
         act = self.new_act(OH, OW, a.C, a.dtype) if st is not None else None
-        partial, nsplit, count = st if st is not None else (None, 0, 0)
-        pptr = 0 if partial is None else (partial if isinstance(partial, int) else partial.data_ptr())
+        units = 1
+        if st is None:
+            pptr, nsplit, count = 0, 0, 0
+        elif st[0] == "unit":
+            (pptr, nsplit, _), = st[1]
+            count = st[2]
+            units = a.C // G // 4
+        else:
+            partial, nsplit, count = st[1]
+            pptr = partial if isinstance(partial, int) else partial.data_ptr()
         self.emit(hip.OP_RESAMPLE, [plain.ptr if plain else 0, act.ptr if act else 0, a.ptr,
                                     pptr, nsplit, count,
                                     gamma.data_ptr() if gamma is not None else 0,
                                     beta.data_ptr() if beta is not None else 0,
-                                    self.B, a.H, a.W, a.C, G, 1 if up else 0, hip.dt_code(a.dtype)], [1e-6])
+                                    self.B, a.H, a.W, a.C, G, 1 if up else 0, hip.dt_code(a.dtype), units], [1e-6])
         return plain, act
 
     # ---- blocks ------------------------------------------------------------------------
@@ -358,11 +382,11 @@ class Program:
         G0, G1 = gn_groups(in_ch), gn_groups(out_ch)
         Gout = gn_groups(out_ch)
         H, Wd = srcs[0].H, srcs[0].W
-        st0, own0 = self.stats_for(srcs, G0)
         tb = self.net.dense_out_ptr(self, mod.idx)
         xr = a0 = None
         if mod.up or mod.down:
             assert len(srcs) == 1
+            st0, own0 = self.stats_for(srcs, G0)
             xr, a0 = self.resample(srcs[0], mod.up, st0, W["gn0_w"], W["gn0_b"], G0)
             short_srcs = [xr]
             segs0 = [(a0, 0, in_ch, 9)]
@@ -372,6 +396,7 @@ class Program:
             segs0 = [(s, 0, s.C, 9) for s in srcs]
             fuse = (self.fused and in_ch <= 512 and self.prologue_pays(srcs[0], out_ch, segs0)
                     and self.tile_ok(srcs[0], out_ch, segs0))
+            st0, own0 = self.stats_for(srcs, G0, units_ok=fuse)
             if fuse:
                 gn0 = (st0, W["gn0_w"], W["gn0_b"], G0, in_ch, True, len(srcs))
             else:
@@ -386,7 +411,6 @@ class Program:
         self.release_stats(st0, own0)
         if a0 is not None:
             self.free_act(a0)
-        st1, own1 = self.stats_for([h1], G1)
         segs1 = [(h1, 0, out_ch, 9)]
         res = None
         if W["has_conv2"]:
@@ -396,6 +420,7 @@ class Program:
             assert len(short_srcs) == 1 and short_srcs[0].C == out_ch
             res = short_srcs[0]
         fuse1 = self.fused and self.prologue_pays(h1, out_ch, segs1) and self.tile_ok(h1, out_ch, segs1)
+        st1, own1 = self.stats_for([h1], G1, units_ok=fuse1)
         a1 = None
         if fuse1:
             gn1 = (st1, W["gn1_w"], W["gn1_b"], G1, out_ch, True, 1)
@@ -417,10 +442,11 @@ class Program:
         W = self.net.w[mod.idx]
         C = mod.in_ch
         G = gn_groups(C)
-        st, own = self.stats_for([x], G)
         segs = [(x, 0, C, 1)]
         a = None
-        if self.fused and self.tile_ok(x, 3 * C, segs):
+        fuse = self.fused and self.tile_ok(x, 3 * C, segs)
+        st, own = self.stats_for([x], G, units_ok=fuse)
+        if fuse:
             gn = (st, W["gn_w"], W["gn_b"], G, C, False, 1)      # 1 tap: the prologue costs nothing extra
         else:
             gn = None
@@ -526,14 +552,15 @@ class Program:
             gnm, head = nxt(), nxt()
             G = gn_groups(h.C)
             gw, hw = net.w[gnm.idx], net.w[head.idx]
-            st, own = self.stats_for([h], G)
             up_pyr = None
             if pyramid is not None:
                 up_pyr, _ = self.resample(pyramid, True)
                 self.free_act(pyramid)
             segs = [(h, 0, h.C, 9)]
             a = None
-            if self.fused and self.prologue_pays(h, IN_CH, segs) and self.tile_ok(h, IN_CH, segs):
+            fuse = self.fused and self.prologue_pays(h, IN_CH, segs) and self.tile_ok(h, IN_CH, segs)
+            st, own = self.stats_for([h], G, units_ok=fuse)
+            if fuse:
                 gn = (st, gw["w"], gw["b"], G, h.C, True, 1)
             else:
                 gn = None

@@ -216,15 +216,28 @@ def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=No
         ws = torch.empty(8 << 20, dtype=torch.uint8, device=DEV)
         ca.workspace, ca.workspace_bytes = ws.data_ptr(), ws.numel()
     if gn is not None:
-        G, gamma, beta, silu, nseg_gn = gn
-        xc = torch.cat([k_.float().cpu() for k_ in keep[:nseg_gn]], 3)          # NHWC, what the device sees
+        G, gamma, beta, silu, nseg_gn = gn[:5]
+        units = len(gn) > 5 and gn[5]
+        srcs = [k_ for k_ in keep if k_.dim() == 4 and k_.shape[:3] == (B, H, W)][:nseg_gn]
+        xc = torch.cat([k_.float().cpu() for k_ in srcs], 3)          # NHWC, what the device sees
         Cg = xc.shape[3]
-        xg = xc.reshape(B, H * W, G, Cg // G)
-        sums = torch.stack([xg.sum((1, 3)), (xg * xg).sum((1, 3))], -1).to(DEV).contiguous()   # [B][G][2]
         gd, bd2 = gamma.to(DEV), beta.to(DEV)
-        keep += [sums, gd, bd2]
-        ca.gn_sums, ca.gn_gamma, ca.gn_beta = sums.data_ptr(), gd.data_ptr(), bd2.data_ptr()
-        ca.gn_nsplit, ca.gn_G, ca.gn_C, ca.gn_silu = 1, G, Cg, int(silu)
+        keep += [gd, bd2]
+        if units:
+            # per-segment statistics over units of 4 channels, split over 2 partial rows per image
+            for i, k_ in enumerate(srcs):
+                xu = k_.float().cpu().reshape(B, 2, H * W // 2, k_.shape[3] // 4, 4)
+                us = torch.stack([xu.sum((2, 4)), (xu * xu).sum((2, 4))], -1).to(DEV).contiguous()   # [B][rows][C/4][2]
+                keep.append(us)
+                ca.gn_seg_sums[i], ca.gn_seg_nsplit[i] = us.data_ptr(), us.shape[1]
+            ca.gn_nsplit = 0
+        else:
+            xg = xc.reshape(B, H * W, G, Cg // G)
+            sums = torch.stack([xg.sum((1, 3)), (xg * xg).sum((1, 3))], -1).to(DEV).contiguous()   # [B][G][2]
+            keep += [sums]
+            ca.gn_sums, ca.gn_nsplit = sums.data_ptr(), 1
+        ca.gn_gamma, ca.gn_beta = gd.data_ptr(), bd2.data_ptr()
+        ca.gn_G, ca.gn_C, ca.gn_silu = G, Cg, int(silu)
         ca.gn_count, ca.gn_eps = H * W * (Cg // G), 1e-6
         ca.seg_gn_mask = (1 << nseg_gn) - 1
     if comb is not None:
@@ -330,13 +343,16 @@ FUSED_CASES = [
     ("patch_gn_comb", 1, 128, 128, [64], 128, 16, 32, False, True),
     ("tap_gn_64", 1, 64, 64, [256, 128], 256, 32, 32, True, False),
     ("tap_gn_8_b2", 2, 8, 8, [128], 256, 32, 32, False, True),
+    ("straddle_384", 1, 16, 16, [256, 128], 128, 32, 32, True, False),        # groups of 12 across 256 | 128
+    ("straddle_384_big", 1, 128, 128, [256, 128], 128, 32, 32, True, False),
 ]
 
 
+@pytest.mark.parametrize("units", [False, True], ids=["groupstats", "unitstats"])
 @pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
-def test_conv_fused_gn_combine_stats(case, dtype, splitk, conv_kernels):
+def test_conv_fused_gn_combine_stats(case, dtype, splitk, conv_kernels, units):
     """conv3x3(silu(GroupNorm(cat(xs)))) [+ 1x1 shortcut of the raw input] [+ Combine] in one
     launch, plus the (sum, sumsq) of the stored output for the next GroupNorm."""
     name, B, H, W, cins, cout, G_in, G_out, shortcut, comb = case
@@ -362,7 +378,13 @@ def test_conv_fused_gn_combine_stats(case, dtype, splitk, conv_kernels):
         off = 0
         for x, c in zip(xs, cins):
             segs.append((x, 1)); weights.append(sw[:, off:off + c]); off += c
-    kw = dict(gn=(G_in, gamma, beta, True, len(cins)), stat_G=G_out, scale=1 / math.sqrt(2.0))
+    # units: the GroupNorm input statistics arrive per source tensor in units of 4 channels (what the
+    # producing convs leave behind) and the output statistics are written in the same form
+    if units:
+        if (Cg // G_in) % 4:
+            pytest.skip("unit statistics need a group size that is a multiple of 4")
+        G_out = cout // 4
+    kw = dict(gn=(G_in, gamma, beta, True, len(cins), units), stat_G=G_out, scale=1 / math.sqrt(2.0))
     ref = ref / math.sqrt(2.0)
     if comb:
         cp, cw, cb = rnd(B, 4, H, W, seed=60), rnd(cout, 4, seed=61), rnd(cout, seed=62)

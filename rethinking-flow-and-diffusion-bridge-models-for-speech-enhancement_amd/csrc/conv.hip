@@ -586,7 +586,7 @@ extern "C" int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int firs
     if (fth && fth[0] == '8') *th = 8;
     return 0;
   }
-  if (first_taps == 9 && (conv_policy() & 2)) {
+  if ((first_taps == 9 || first_taps == 1) && (conv_policy() & 2)) {   // (1x1: the shared-tap path alone)
     int tw = 0, tr = 0;
     if (W % 16 == 0 && H % 4 == 0) { tw = 16; tr = 4; }
     else if (W % 8 == 0 && H % 8 == 0) { tw = 8; tr = 8; }

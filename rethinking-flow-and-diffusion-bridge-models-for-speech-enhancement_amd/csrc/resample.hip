@@ -134,6 +134,99 @@ __global__ void __launch_bounds__(256) resample2x_kernel(
   }
 }
 
+// Tiled variant for the fused GroupNorm+SiLU case: the per-output kernel above evaluates the
+// activation once per TAP (16x per input element when upsampling, 4x when downsampling) and is
+// VALU-bound there.  Here a workgroup stages an input tile with its halo ONCE - raw and activated,
+// as f32 - in LDS and forms every output of the tile from it, in the same tap order as above
+// (bit-identical results).  Tile: 8 x 8 output pixels (down) / 8 x 8 input pixels (up) x 16 channels.
+template <typename T, bool UP, bool PLAIN>
+__global__ void __launch_bounds__(256) resample2x_tile_kernel(
+    T* __restrict__ out_plain, T* __restrict__ out_act, const T* __restrict__ in,
+    const float* __restrict__ stats, int nsplit, double inv_count, float eps,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    int H, int W, int C, int G, int upg, int tiles_x) {
+  constexpr int VW = DT<T>::vecw;
+  constexpr int CCH = 16, CV = CCH / VW;          // channels per workgroup, 16-byte vectors of them
+  constexpr int PS = CCH + 4;                       // LDS pixel stride in floats (bank spread)
+  constexpr int IH = UP ? 10 : 18, IW = UP ? 10 : 18;       // staged input tile (with halo)
+  constexpr int OHT = UP ? 16 : 8, OWT = UP ? 16 : 8;       // output tile
+  extern __shared__ float s_all[];                  // [2][C] scale/shift | raw [IH*IW][PS] | act [IH*IW][PS]
+  __shared__ double s_red[8 * 32 * 2];
+  float* s_ss = s_all;
+  float* s_raw = s_all + 2 * C;
+  float* s_act = s_raw + IH * IW * PS;
+  const int b = blockIdx.z;
+  const int c0 = blockIdx.y * CCH;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+  // input coordinates of the staged tile's first pixel
+  const int iy0 = UP ? ty * 8 - 1 : ty * 16 - 1, ix0 = UP ? tx * 8 - 1 : tx * 16 - 1;
+  gn_scale_shift(s_ss, s_red, stats, nsplit, inv_count, eps, b, C, G, gamma, beta, upg);
+  const T* img = in + (int64_t)b * H * W * C;
+  for (int i = threadIdx.x; i < IH * IW * CV; i += 256) {
+    const int v = i % CV, px = i / CV;
+    const int iy = iy0 + px / IW, ix = ix0 + px % IW;
+    float x[VW], a[VW];
+    const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+    if (ok) {
+      Vec16<T>::load(img + ((int64_t)iy * W + ix) * C + c0 + v * VW, x);
+#pragma unroll
+      for (int k = 0; k < VW; ++k) a[k] = silu_t<T>(x[k] * s_ss[c0 + v * VW + k] + s_ss[C + c0 + v * VW + k]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < VW; ++k) x[k] = a[k] = 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < VW; ++k) {
+      if (PLAIN) s_raw[px * PS + v * VW + k] = x[k];
+      s_act[px * PS + v * VW + k] = a[k];
+    }
+  }
+  __syncthreads();
+  const int OH = UP ? 2 * H : H / 2, OW = UP ? 2 * W : W / 2;
+  for (int o = threadIdx.x; o < OHT * OWT * CV; o += 256) {
+    const int v = o % CV, op = o / CV;
+    const int oyl = op / OWT, oxl = op % OWT;
+    const int oy = ty * OHT + oyl, ox = tx * OWT + oxl;
+    constexpr int NT = UP ? 2 : 4;
+    int ys[NT], xs[NT];        // tile-local input coordinates of the taps
+    float wy[NT], wx[NT];
+    if (UP) {
+      // global input row of tap 0: (oy odd ? oy/2 : oy/2 - 1); tile-local = that - iy0
+      const int ly = (oyl >> 1) + 1, lx = (oxl >> 1) + 1;        // tile-local coordinates of input pixel (oy/2, ox/2)
+      if (oyl & 1) { ys[0] = ly; wy[0] = 0.75f; ys[1] = ly + 1; wy[1] = 0.25f; }
+      else         { ys[0] = ly - 1; wy[0] = 0.25f; ys[1] = ly; wy[1] = 0.75f; }
+      if (oxl & 1) { xs[0] = lx; wx[0] = 0.75f; xs[1] = lx + 1; wx[1] = 0.25f; }
+      else         { xs[0] = lx - 1; wx[0] = 0.25f; xs[1] = lx; wx[1] = 0.75f; }
+    } else {
+      const float w4[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        ys[k] = 2 * oyl + k; wy[k] = w4[k];          // global 2 oy - 1 + k, minus iy0 = 16 ty - 1
+        xs[k] = 2 * oxl + k; wx[k] = w4[k];
+      }
+    }
+    float accp[VW], acca[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) accp[k] = acca[k] = 0.f;
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int bx = 0; bx < NT; ++bx) {
+        const float wgt = wy[a] * wx[bx];
+        const float* ra = s_act + (ys[a] * IW + xs[bx]) * PS + v * VW;
+        const float* rr = s_raw + (ys[a] * IW + xs[bx]) * PS + v * VW;
+#pragma unroll
+        for (int k = 0; k < VW; ++k) {
+          if (PLAIN) accp[k] += wgt * rr[k];
+          acca[k] += wgt * ra[k];
+        }
+      }
+    const int64_t oidx = (((int64_t)b * OH + oy) * OW + ox) * C + c0 + v * VW;
+    if (PLAIN) Vec16<T>::store(out_plain + oidx, accp);
+    Vec16<T>::store(out_act + oidx, acca);
+  }
+}
+
 extern "C" int fdbm_resample2x(void* out_plain, void* out_act, const void* in, const float* stats,
                                int nsplit, int64_t count, float eps,
                                const float* gamma, const float* beta, int B, int H, int W, int C,
@@ -155,6 +248,39 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
   const int vw = dtype == FDBM_BF16 ? 8 : 4;
   FDBM_CHECK(C % vw == 0, "fdbm_resample2x: C=%d must be a multiple of %d", C, vw);
   FDBM_CHECK(up || (H % 2 == 0 && W % 2 == 0), "fdbm_resample2x: downsampling needs even H, W (got %d x %d)", H, W);
+  hipStream_t st = (hipStream_t)stream;
+  // fused GroupNorm+SiLU on maps that tile: the LDS-staged kernel (one activation per input element)
+  if (out_act && C % 16 == 0 && (up ? (H % 8 == 0 && W % 8 == 0) : (H % 16 == 0 && W % 16 == 0))) {
+    const int tiles_x = up ? W / 8 : W / 16, tiles_y = up ? H / 8 : H / 16;
+    const int npx = up ? 100 : 324;
+    const size_t smem = (2 * (size_t)C + 2 * (size_t)npx * 20) * sizeof(float);
+    dim3 grid(tiles_x * tiles_y, C / 16, B);
+#define RT(TT, U, P)                                                                                     \
+  do {                                                                                                   \
+    static bool attr = false;                                                                            \
+    if (!attr) {                                                                                         \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&resample2x_tile_kernel<TT, U, P>),        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);                  \
+      attr = true;                                                                                       \
+    }                                                                                                    \
+    resample2x_tile_kernel<TT, U, P><<<grid, 256, smem, st>>>((TT*)out_plain, (TT*)out_act, (const TT*)in, stats, nsplit, \
+                                                              inv_count, eps, gamma, beta, H, W, C, G, stat_units, tiles_x); \
+  } while (0)
+#define RT_DISPATCH(TT)                                                              \
+  do {                                                                               \
+    if (up) { if (out_plain) RT(TT, true, true); else RT(TT, true, false); }         \
+    else    { if (out_plain) RT(TT, false, true); else RT(TT, false, false); }       \
+  } while (0)
+    if (smem <= 64 * 1024) {
+      if (dtype == FDBM_BF16) RT_DISPATCH(bf16_t);
+      else if (dtype == FDBM_F32) RT_DISPATCH(float);
+      else FDBM_CHECK(false, "fdbm_resample2x: bad dtype %d", dtype);
+      FDBM_LAUNCH_CHECK("fdbm_resample2x(tile)");
+      return 0;
+    }
+#undef RT_DISPATCH
+#undef RT
+  }
   const int OH = up ? 2 * H : H / 2, OW = up ? 2 * W : W / 2;
   const int64_t total = (int64_t)OH * OW * (C / vw);
   int chunks = (int)((total + 1023) / 1024);
@@ -162,7 +288,6 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
   if (chunks < 1) chunks = 1;
   dim3 grid(chunks, B);
   const size_t smem = out_act ? 2 * (size_t)C * sizeof(float) : 0;
-  hipStream_t st = (hipStream_t)stream;
 #define RS(TT, U, P, A) resample2x_kernel<TT, U, P, A><<<grid, 256, smem, st>>>((TT*)out_plain, (TT*)out_act, (const TT*)in, stats, nsplit, inv_count, eps, gamma, beta, H, W, C, G, chunks, stat_units)
 #define RS_DISPATCH(TT)                                                         \
   do {                                                                          \

@@ -153,9 +153,11 @@ def test_groupnorm(dtype, tol, C0, C1, G):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 4e-2)])
+@pytest.mark.parametrize("shape", [(2, 32, 8, 12, 8), (2, 48, 32, 48, 12), (1, 128, 16, 32, 32)],
+                         ids=["per_output", "tiled_c48", "tiled_c128"])        # tiled: LDS-staged kernel (maps that tile by 16)
 @pytest.mark.parametrize("up", [False, True])
-def test_resample2x(dtype, tol, up):
-    B, C, H, W, G = 2, 32, 8, 12, 8
+def test_resample2x(dtype, tol, up, shape):
+    B, C, H, W, G = shape
     x = rnd(B, C, H, W, seed=5)
     d = nhwc(x, dtype)
     xs = nchw(d)
@@ -172,6 +174,14 @@ def test_resample2x(dtype, tol, up):
              hip.ptr(bd), B, H, W, C, G, int(up), hip.dt_code(dtype))
     assert (nchw(o_plain) - ref_plain).abs().max() < tol
     assert (nchw(o_act) - ref_act).abs().max() < tol
+    # activated output only, statistics as partial unit sums (what a producing conv leaves behind)
+    if (C // G) % 4 == 0:
+        xu = d.float().cpu().reshape(B, 2, H * W // 2, C // 4, 4)
+        us = torch.stack([xu.sum((2, 4)), (xu * xu).sum((2, 4))], -1).to(DEV).contiguous()     # [B][2][C/4][2]
+        o_act2 = torch.empty_like(o_act)
+        hip.call("fdbm_resample2x_units", 0, hip.ptr(o_act2), hip.ptr(d), hip.ptr(us), 2, C // G // 4, H * W * (C // G), 1e-6,
+                 hip.ptr(gd), hip.ptr(bd), B, H, W, C, G, int(up), hip.dt_code(dtype))
+        assert (nchw(o_act2) - ref_act).abs().max() < tol
     # plain only, 4-channel f32 pyramid flavour
     if dtype == torch.float32:
         p = rnd(B, 4, H, W, seed=6)

@@ -204,6 +204,13 @@ typedef struct {
    * segments must be segments 0 .. n-1 (seg_gn_mask = 2^n - 1). */
   const float* gn_seg_sums[FDBM_MAX_SEG];
   int32_t gn_seg_nsplit[FDBM_MAX_SEG];
+  /* optional: ZERO-INITIALISED scratch of at least M*Cout*4 + 4096 bytes.  When given, the
+   * wave-per-tap kernel may split the input-channel chunks of a small-map convolution over several
+   * workgroups that add their partial tiles into it (fp32 atomics; the summation order, and so the
+   * last bit of the result, then varies from run to run); the workgroup that finishes last applies
+   * the epilogue and leaves the scratch zeroed for the next launch.  NULL: never split. */
+  void* acc_ws;
+  int64_t acc_ws_bytes;
 } fdbm_conv_args;
 
 int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream);

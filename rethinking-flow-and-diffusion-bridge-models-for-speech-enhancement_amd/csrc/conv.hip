@@ -705,7 +705,25 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   }
   hipStream_t st = (hipStream_t)stream;
   if (kind == 1) return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
-  if (kind == 2) { p.ksplit = 1; p.w = a->w_frag; /* p.partial: unused (diagnostic stamps only) */ return fdbm_launch_conv_tap(p, a->dt_in, a->dt_out, th, bn / 16, st); }
+  if (kind == 2) {
+    p.w = a->w_frag;
+    p.ksplit = 1;
+    p.partial = reinterpret_cast<float*>(a->workspace);        // (ksplit 1: diagnostic stamps only)
+    // split the channel chunks over workgroups when the tiles alone leave most of the chip idle
+    int nchunks = 0;
+    for (int s = 0; s < a->nseg; ++s) nchunks += (a->seg[s].cin + kc - 1) / kc;
+    const int tw = th, tr = tw == 16 ? 4 : tw == 8 ? 8 : 4;
+    const int64_t blocks = (int64_t)a->B * (a->H / tr) * (a->W / tw) * ((a->Cout + bn - 1) / bn);
+    const int64_t need = M * a->Cout * 4 + blocks * 4;
+    static const char* smin = getenv("FDBM_TAP_SPLIT_MIN");     // experiments
+    if (a->acc_ws && a->acc_ws_bytes >= need && blocks <= 128 && nchunks >= (smin ? atoi(smin) : 8)) {
+      int ks = (int)(256 / blocks);
+      if (ks > nchunks / 2) ks = nchunks / 2;
+      if (ks > 8) ks = 8;
+      if (ks > 1) { p.ksplit = ks; p.partial = reinterpret_cast<float*>(a->acc_ws); }
+    }
+    return fdbm_launch_conv_tap(p, a->dt_in, a->dt_out, th, bn / 16, st);
+  }
   const int kg = plan_kgroups(((M + bm - 1) / bm) * ((a->Cout + bn - 1) / bn), bm, bn, nk);
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_BF16) return launch_conv_tile<bf16_t, bf16_t>(p, bm, bn, kg, st);
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_F32) return launch_conv_tile<bf16_t, float>(p, bm, bn, kg, st);

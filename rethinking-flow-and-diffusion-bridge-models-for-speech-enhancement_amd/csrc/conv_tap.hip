@@ -246,14 +246,25 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
       if constexpr (S == 0) { wA0[j] = v0; wA1[j] = v1; wAs[j] = vs; } else { wB0[j] = v0; wB1[j] = v1; wBs[j] = vs; }
     }
   };
-  int s1 = 0, c1 = 0, kb1 = 0;            // chunk 1 (or chunk 0 again when there is only one)
+  // split over workgroups (p.ksplit > 1, grid.z): this workgroup owns chunks [zb, ze) of the conv and
+  // adds its partial tile into the zeroed fp32 scratch p.partial; the workgroup whose add comes last
+  // applies the epilogue (and leaves the scratch zeroed).  For maps so small that the tiles alone
+  // occupy a fraction of the chip and the chain over the chunks is the whole run time.
+  int ntotal = 0;
+  for (int s_ = 0; s_ < p.nseg; ++s_) ntotal += seg_nch(s_);
+  const int zper = (ntotal + p.ksplit - 1) / p.ksplit;
+  const int zraw = (int)blockIdx.z * zper;
+  const int nmine = max(min(ntotal, zraw + zper) - zraw, 0);   // (a trailing workgroup may own nothing: it adds zeros)
+  const int zb = min(zraw, ntotal - 1);
+  for (int i = 0; i < zb; ++i) (void)advance(cs, cc, kbase);
+  int s1 = cs, c1 = cc, kb1 = kbase;      // chunk 1 (or chunk 0 again when there is only one)
   bool more = advance(s1, c1, kb1);
   int s2 = s1, c2 = c1, kb2 = kb1;        // chunk 2
   if (more) more = advance(s2, c2, kb2);
   STAMP_RT(60);
   STAMP(0);
-  load_patch(S0{}, 0, 0);
-  load_w(S0{}, 0, 0, 0);
+  load_patch(S0{}, cs, cc);
+  load_w(S0{}, cs, cc, kbase);
   load_patch(S1{}, s1, c1);
   load_w(S1{}, s1, c1, kb1);
   STAMP(1);
@@ -340,11 +351,9 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
     s1 = s2; c1 = c2; kb1 = kb2;
     if (more) more = advance(s2, c2, kb2);
   };
-  int ntotal = 0;
-  for (int s_ = 0; s_ < p.nseg; ++s_) ntotal += seg_nch(s_);
-  for (int c = 0; c < ntotal; c += 2) {
+  for (int c = 0; c < nmine; c += 2) {
     chunk(S0{});
-    if (c + 1 < ntotal) chunk(S1{});
+    if (c + 1 < nmine) chunk(S1{});
   }
   (void)cc; (void)kbase;
 
@@ -374,16 +383,54 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   __syncthreads();
 
   STAMP(28);
-  // ---- epilogue, output tile t = j * MT + i handled by wave t mod 8 -----------------------------------------
   const int Cout = p.Cout;
+  const bool split = p.ksplit > 1;
+  if (split) {
+    // partial tile -> scratch (fp32 atomics at the device coherence point), then count this workgroup in
+    for (int t = wave; t < MT * NT; t += 8) {
+      const int j = t / MT, i = t - j * MT;
+      const f32x4 s = (red[t * 64 + lane] + red[SL4 + t * 64 + lane]) + (red[2 * SL4 + t * 64 + lane] + red[3 * SL4 + t * 64 + lane]);
+      const int y = y0 + i * RPM + frow / TW, x = x0 + frow % TW;
+      const int64_t m = img + (int64_t)y * W + x;
+      const int n = n0 + j * 16 + fk * 4;
+      if (n < Cout) {
+        float* dst = p.partial + m * Cout + n;
+        atomicAdd(dst, s[0]); atomicAdd(dst + 1, s[1]); atomicAdd(dst + 2, s[2]); atomicAdd(dst + 3, s[3]);
+      }
+    }
+    // No agent-scope fence here: a fence would write back this XCD's whole L2 (the previous kernels' output,
+    // tens of microseconds).  Everything exchanged through the scratch is an agent-scope atomic - performed
+    // at the device coherence point and acknowledged before vmcnt reaches 0 - so waiting for this workgroup's
+    // atomics (workgroup-scope release = s_waitcnt, then the barrier) orders them before the counter add.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    int* counter = reinterpret_cast<int*>(p.partial + (int64_t)p.B * H * W * Cout) + blockIdx.x * gridDim.y + blockIdx.y;
+    int* s_flag = reinterpret_cast<int*>(s_stat + 128);
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *s_flag = (old == p.ksplit - 1);
+      if (old == p.ksplit - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    }
+    __syncthreads();
+    if (!*s_flag) return;                   // (whole workgroup)
+  }
+  // ---- epilogue, output tile t = j * MT + i handled by wave t mod 8 -----------------------------------------
   const bool do_stat = p.stat_out != nullptr;
   const int scpg = do_stat ? Cout / p.stat_G : 1;
   for (int t = wave; t < MT * NT; t += 8) {
     const int j = t / MT, i = t - j * MT;
-    const f32x4 s = (red[t * 64 + lane] + red[SL4 + t * 64 + lane]) + (red[2 * SL4 + t * 64 + lane] + red[3 * SL4 + t * 64 + lane]);
+    f32x4 s = (red[t * 64 + lane] + red[SL4 + t * 64 + lane]) + (red[2 * SL4 + t * 64 + lane] + red[3 * SL4 + t * 64 + lane]);
     const int y = y0 + i * RPM + frow / TW, x = x0 + frow % TW;
     const int64_t m = img + (int64_t)y * W + x;
     const int n = n0 + j * 16 + fk * 4;
+    if (split && n < Cout) {                // the complete sums, read at the coherence point; scratch back to zero
+      float* src = p.partial + m * Cout + n;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s[r] = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(src + r, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
     float v[4] = {s[0], s[1], s[2], s[3]};
     const bool live = n < Cout;
     if (live) conv_epilogue4<TO>(p, m, b, n, v);
@@ -417,7 +464,7 @@ static int launch_tap(const ConvParams& p, hipStream_t st) {
   constexpr int PBUF = (TR + 2) * (TW + 2) * 128;
   constexpr int SLAB = MT * NT * 1024;
   constexpr int MAIN = (2 * PBUF > 4 * SLAB) ? 2 * PBUF : 4 * SLAB;
-  constexpr int SMEM = MAIN + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 4 * 2;
+  constexpr int SMEM = MAIN + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 4 * 2 + 16;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tap_kernel<T, TO, TW, MT, NT, GNP>),
@@ -429,7 +476,7 @@ static int launch_tap(const ConvParams& p, hipStream_t st) {
     attr_set = true;
   }
   const int tiles_x = p.W / TW, tiles_y = p.H / TR;
-  dim3 grid((unsigned)(p.B * tiles_x * tiles_y), (unsigned)((p.Cout + 16 * NT - 1) / (16 * NT)));
+  dim3 grid((unsigned)(p.B * tiles_x * tiles_y), (unsigned)((p.Cout + 16 * NT - 1) / (16 * NT)), (unsigned)p.ksplit);
   conv_tap_kernel<T, TO, TW, MT, NT, GNP><<<grid, TAP_NTHR, SMEM, st>>>(p, tiles_x, tiles_y);
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm(tap)");
   return 0;

@@ -176,6 +176,7 @@ class Program:
         self.keep = []         # tensors that must outlive the program
         self.keep_conv = []    # ConvArgs structs, one per conv op, in op order
         self.splitk_ws = None
+        self.acc_ws = None
         self.fused = net.fused
         # (sum, sumsq) slots [slot][B][32][2] that conv epilogues accumulate into with atomics;
         # zeroed by ONE memset at the head of every forward
@@ -299,6 +300,15 @@ class Program:
         ca.w = wpack.data_ptr()
         if self.plan(a0, cout, segs)["kind"] == 2:
             ca.w_frag = self.net.frag_weight(wpack).data_ptr()
+            if self.fused and a0.M * cout * 4 <= (4 << 20):
+                # throughput mode: small-map convs may split their channel chunks over workgroups and
+                # combine through this zeroed scratch (fp32 atomics: run-to-run last-bit variation, as
+                # with the GroupNorm statistics); the parity mode stays deterministic
+                need = a0.M * cout * 4 + 65536
+                if self.acc_ws is None or self.acc_ws.numel() < need:
+                    self.acc_ws = torch.zeros(max(need, (4 << 20) + 65536), dtype=torch.uint8, device=self.dev)
+                    self.keep.append(self.acc_ws)
+                ca.acc_ws, ca.acc_ws_bytes = self.acc_ws.data_ptr(), self.acc_ws.numel()
         ca.bias = bias.data_ptr() if bias is not None else 0
         ca.tbias = tbias if tbias else 0
         ca.tbias_stride = tb_stride

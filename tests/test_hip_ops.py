@@ -222,9 +222,13 @@ def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=No
     ca.out = out.data_ptr()
     ca.B, ca.H, ca.W, ca.Cout, ca.CoutPad = B, H, W, cout, cpad
     ca.dt_in, ca.dt_out = hip.dt_code(dtype), hip.dt_code(out_dtype)
+    acc = None
     if splitk:
         ws = torch.empty(8 << 20, dtype=torch.uint8, device=DEV)
         ca.workspace, ca.workspace_bytes = ws.data_ptr(), ws.numel()
+        # zeroed scratch: lets the wave-per-tap kernel split small-map convs over workgroups
+        acc = torch.zeros(B * H * W * cout * 4 + 4096, dtype=torch.uint8, device=DEV)
+        ca.acc_ws, ca.acc_ws_bytes = acc.data_ptr(), acc.numel()
     if gn is not None:
         G, gamma, beta, silu, nseg_gn = gn[:5]
         units = len(gn) > 5 and gn[5]
@@ -261,6 +265,14 @@ def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=No
         ca.stat_out, ca.stat_G, ca.stat_nsplit = st.data_ptr(), stat_G, 3
     hip.call("fdbm_conv_igemm", ca)
     torch.cuda.synchronize()
+    if acc is not None:
+        assert not acc.any(), "the accumulation scratch must be left zeroed"
+        if st is not None:
+            st.zero_()
+        out.fill_(float("nan"))
+        hip.call("fdbm_conv_igemm", ca)          # and a second launch on it gives the same result
+        torch.cuda.synchronize()
+        assert not acc.any()
     if stat_G:
         return nchw(out), keep, st.cpu().sum(1)
     return nchw(out), keep, rd

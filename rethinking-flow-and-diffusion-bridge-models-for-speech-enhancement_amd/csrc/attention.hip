@@ -2,10 +2,16 @@
 //   out[b][i][:] = sum_j softmax_j(q_i . k_j * C^-0.5) v_j      over all N = H*W tokens.
 //
 // 0.04 % of the network's flops and latency-bound (N = T tokens at the 16-row level, 4*T/64
-// at the bottleneck), so this is an fp32 flash-style kernel on the vector ALU: 16 queries
-// per workgroup, keys/values streamed through LDS in tiles of 32, online softmax with
-// 16-lane shuffle reductions, fp32 accumulation whatever the storage dtype.
-#include "common.h"
+// at the bottleneck).  Two kernels:
+//  * attention_kernel: fp32 flash-style on the vector ALU (any N, C; the parity mode's kernel):
+//    16 queries per workgroup, keys/values streamed through LDS in tiles of 32, online softmax
+//    with 16-lane shuffle reductions, fp32 accumulation whatever the storage dtype.
+//  * attention_mfma_kernel: bf16 storage, N % 64 == 0, C % 64 == 0: the same 16 queries per
+//    workgroup, but Q.K^T and P.V on the matrix cores (4 waves: 16 keys each of a 64-key tile for
+//    the scores, C/4 output channels each for P.V), scores of all N keys kept in LDS (two-pass
+//    softmax, no running rescale), V staged TRANSPOSED in LDS so that its MFMA operand is
+//    key-contiguous.  ~6x shorter than the VALU kernel at N = C = 256, batch 1.
+#include "conv_common.h"
 
 #define ATT_QB 16
 #define ATT_KB 32
@@ -125,6 +131,124 @@ __global__ void __launch_bounds__(256) attention_kernel(T* __restrict__ out, con
   }
 }
 
+// LDS rows: K tile [64 keys][C bf16 + 16 B pad]; V^T tile [C channels][64 keys bf16 + 16 B pad], its
+// 16-byte slots (8 keys) XOR-swizzled with (channel >> 3) & 7; scores [16][N] f32; P [16][N bf16 + 16 B].
+__global__ void __launch_bounds__(256) attention_mfma_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ qkv,
+                                                             int N, int C, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
+  const int KRS = C * 2 + 16;                 // K-tile row stride (bytes)
+  constexpr int VRS = 64 * 2 + 16;            // V^T-tile row stride
+  const int PRS = N * 2 + 16;                 // P row stride
+  const int kv_bytes = max(64 * KRS, C * VRS);
+  unsigned char* s_kv = smem_a;
+  float* s_S = reinterpret_cast<float*>(smem_a + kv_bytes);                 // [16][N]
+  unsigned char* s_P = smem_a + kv_bytes + 16 * N * 4;                      // [16][PRS]
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fk = lane >> 4;
+  const bf16_t* base = qkv + (int64_t)b * N * 3 * C;
+  const int nch = C / 8;                      // 16-byte chunks per row
+  const int nks = C / 32;                     // MFMA k-steps over the channels (<= 8)
+
+  // ---- Q tile -> LDS -> operand registers (B operand: column = query) ------------------------------
+  for (int i = tid; i < 16 * nch; i += 256) {
+    const int r = i / nch, ch = i - r * nch;
+    *reinterpret_cast<uint4*>(s_kv + r * KRS + ch * 16) =
+        *reinterpret_cast<const uint4*>(base + (int64_t)(q0 + r) * 3 * C + ch * 8);
+  }
+  __syncthreads();
+  uint4 qf[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+    qf[ks] = ks < nks ? *reinterpret_cast<const uint4*>(s_kv + frow * KRS + (ks * 4 + fk) * 16) : uint4{0u, 0u, 0u, 0u};
+  __syncthreads();
+
+  // ---- scores: S[query][key] = scale * q . k, 64 keys per tile, 16 per wave ---------------------------
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    for (int i = tid; i < 64 * nch; i += 256) {
+      const int r = i / nch, ch = i - r * nch;
+      *reinterpret_cast<uint4*>(s_kv + r * KRS + ch * 16) =
+          *reinterpret_cast<const uint4*>(base + (int64_t)(k0 + r) * 3 * C + C + ch * 8);
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks)
+      if (ks < nks) {
+        const uint4 kf = *reinterpret_cast<const uint4*>(s_kv + (wave * 16 + frow) * KRS + (ks * 4 + fk) * 16);
+        Mfma<bf16_t>::run(kf, qf[ks], acc);      // rows = keys, columns = queries
+      }
+    // lane (query frow, fk) holds keys k0 + 16 wave + 4 fk + 0..3
+    *reinterpret_cast<f32x4*>(s_S + frow * N + k0 + wave * 16 + fk * 4) = acc * scale;
+    __syncthreads();
+  }
+
+  // ---- softmax over the N keys of each query: 16 threads per query ------------------------------------
+  {
+    const int q = tid >> 4, part = tid & 15;
+    const int per = N / 16;
+    const float* row = s_S + q * N + part * per;
+    float m = -INFINITY;
+    for (int i = 0; i < per; ++i) m = fmaxf(m, row[i]);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float l = 0.f;
+    for (int i = 0; i < per; ++i) l += __expf(row[i] - m);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) l += __shfl_xor(l, off);
+    const float inv = 1.0f / l;
+    bf16_t* prow = reinterpret_cast<bf16_t*>(s_P + q * PRS) + part * per;
+    for (int i = 0; i < per; ++i) prow[i] = (bf16_t)(__expf(row[i] - m) * inv);
+  }
+  __syncthreads();
+
+  // ---- O = P . V: wave w owns channels [w C/4, (w+1) C/4), 64 keys per tile -------------------------
+  const int ntw = C / 64;                     // 16-channel n-tiles per wave (<= 4)
+  f32x4 oacc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    // V tile transposed into LDS: a thread takes 8 channels of TWO consecutive keys and writes 8 dwords
+    // {v[2kp][c], v[2kp+1][c]}; within a wave 8 chunks x 8 key pairs -> 64 distinct banks
+    for (int i = tid; i < 32 * nch; i += 256) {
+      const int ch = (i & 7) | ((i >> 6) % (nch / 8)) << 3;
+      const int kp = ((i >> 3) & 7) | ((i >> 6) / (nch / 8)) << 3;
+      const bf16_t* src = base + (int64_t)(k0 + 2 * kp) * 3 * C + 2 * C + ch * 8;
+      const uint4 lo = *reinterpret_cast<const uint4*>(src);
+      const uint4 hi = *reinterpret_cast<const uint4*>(src + 3 * C);
+      const unsigned short* l16 = reinterpret_cast<const unsigned short*>(&lo);
+      const unsigned short* h16 = reinterpret_cast<const unsigned short*>(&hi);
+      const int slot = (kp >> 2) ^ (ch & 7);
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        *reinterpret_cast<unsigned*>(s_kv + (ch * 8 + e) * VRS + slot * 16 + (kp & 3) * 4) =
+            (unsigned)l16[e] | ((unsigned)h16[e] << 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const uint4 pf = *reinterpret_cast<const uint4*>(s_P + frow * PRS + (k0 + ks * 32 + fk * 8) * 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < ntw) {
+          const int c = (wave * ntw + j) * 16 + frow;
+          const uint4 vf = *reinterpret_cast<const uint4*>(s_kv + c * VRS + (((ks * 4 + fk) ^ ((c >> 3) & 7)) << 4));
+          Mfma<bf16_t>::run(vf, pf, oacc[j]);    // rows = channels, columns = queries
+        }
+    }
+    __syncthreads();
+  }
+  bf16_t* dst = out + ((int64_t)b * N + q0 + frow) * C;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < ntw) {
+      const int c = (wave * ntw + j) * 16 + fk * 4;
+      const bf16x4 t = {(bf16_t)oacc[j][0], (bf16_t)oacc[j][1], (bf16_t)oacc[j][2], (bf16_t)oacc[j][3]};
+      *reinterpret_cast<bf16x4*>(dst + c) = t;
+    }
+}
+
 extern "C" int fdbm_attention(void* out, const void* qkv, int B, int N, int C, int dtype, void* stream) {
   FDBM_CHECK(out && qkv, "fdbm_attention: null pointer");
   FDBM_CHECK(C % 8 == 0 && C <= 256, "fdbm_attention: C=%d must be a multiple of 8, <= 256", C);
@@ -133,7 +257,14 @@ extern "C" int fdbm_attention(void* out, const void* qkv, int B, int N, int C, i
   dim3 grid(cdiv(N, ATT_QB), B);
   const float scale = 1.0f / sqrtf((float)C);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FDBM_BF16) {
+  if (dtype == FDBM_BF16 && N % 64 == 0 && N <= 1024 && C % 64 == 0) {
+    const int krs = C * 2 + 16;
+    const size_t kv = (size_t)(64 * krs > C * 144 ? 64 * krs : C * 144);
+    const size_t sm = kv + (size_t)16 * N * 4 + (size_t)16 * (N * 2 + 16);
+    static bool setm = false;
+    if (!setm) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); setm = true; }
+    attention_mfma_kernel<<<dim3(N / 16, B), 256, sm, st>>>((bf16_t*)out, (const bf16_t*)qkv, N, C, scale);
+  } else if (dtype == FDBM_BF16) {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); set = true; }
     attention_kernel<bf16_t><<<grid, 256, smem, st>>>((bf16_t*)out, (const bf16_t*)qkv, N, C, scale);

@@ -421,7 +421,7 @@ def test_conv_fused_gn_combine_stats(case, dtype, splitk, conv_kernels, units):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
-@pytest.mark.parametrize("N,C", [(64, 32), (256, 256), (40, 96), (16, 192)])
+@pytest.mark.parametrize("N,C", [(64, 32), (256, 256), (40, 96), (16, 192), (64, 64), (128, 192), (512, 256)])
 def test_attention(dtype, tol, N, C):
     B = 2
     qkv = rnd(B, N, 3 * C, seed=80).to(dtype)

@@ -582,8 +582,6 @@ extern "C" int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int firs
   if ((conv_policy() & 1) && first_taps == 9 && H % 8 == 0 && W % 16 == 0 && *ksplit == 1 && tiles16 >= min_tiles) {
     *kind = 1;
     *th = (H % 16 == 0 && tiles16 >= 256) ? 16 : 8;
-    static const char* fth = getenv("FDBM_PATCH_TH");          // experiments
-    if (fth && fth[0] == '8') *th = 8;
     return 0;
   }
   if ((first_taps == 9 || first_taps == 1) && (conv_policy() & 2)) {   // (1x1: the shared-tap path alone)
@@ -704,7 +702,13 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     p.stat_out = a->stat_out; p.stat_G = a->stat_G; p.stat_nsplit = a->stat_nsplit;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (kind == 1) return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
+  if (kind == 1) {
+    // 8-row tiles let two workgroups share a CU (their load / epilogue phases then overlap the other's
+    // MFMAs) as long as the GroupNorm table stays within 2 KiB: measured +2...11 % over 16-row tiles
+    static const char* fth = getenv("FDBM_PATCH_TH");          // experiments: "16" keeps the plan's choice
+    if (!(fth && fth[0] == '1') && (!a->gn_sums && !gn_units ? true : a->gn_C <= 256)) th = 8;
+    return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
+  }
   if (kind == 2) {
     p.w = a->w_frag;
     p.ksplit = 1;

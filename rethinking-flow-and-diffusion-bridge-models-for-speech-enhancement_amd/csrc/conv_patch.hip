@@ -39,7 +39,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   unsigned char* s_patch = smem;                          // 2 x PBUF
   unsigned char* s_w = smem + 2 * PBUF;                   // 2 x WBUF
   float2* s_gn = reinterpret_cast<float2*>(smem + 2 * PBUF + 2 * WBUF);                       // [gn_C]
-  float* s_stat = reinterpret_cast<float*>(smem + 2 * PBUF + 2 * WBUF + (GNP ? CONV_GN_MAXC * 8 : 0));  // [32][2] + [32][2]
+  float* s_stat = reinterpret_cast<float*>(smem + 2 * PBUF + 2 * WBUF + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0));  // [32][2] + [32][2] (after the table)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -343,11 +343,14 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
 template <typename T, typename TO, int TH, int BN, bool GNP>
 static int launch_patch(const ConvParams& p, hipStream_t st) {
   constexpr int NTHR = 64 * (TH / 4) * (BN / 64);
-  constexpr int SMEM = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 4 * 2;
+  constexpr int SMEM_MAX = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 4 * 2;
+  // the GroupNorm table takes what the layer needs: with 8-row tiles and <= 256 normalised channels two
+  // workgroups fit the 160 KiB of a CU
+  const int SMEM = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0) + 64 * 4 * 2;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<T, TO, TH, BN, GNP>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_MAX);
     if (e != hipSuccess) {
       fdbm_set_error("fdbm_conv_igemm(patch): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 2;

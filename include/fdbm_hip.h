@@ -88,6 +88,12 @@ int fdbm_dense_rows(float* out, const float* act, const float* w, const float* b
  * (o, ky, kx, c), out dtype `dt_out` [B][H][W][nf]. */
 int fdbm_conv_stem(void* out, const float* in, const float* w, const float* bias, int B, int H,
                    int W, int nf, int dt_out, void* stream);
+/* the same, also accumulating the UNIT statistics of the stored output ((sum, sumsq) per image and
+ * 4 channels, [B][stat_nsplit][nf/4][2], atomics into a zeroed buffer - the layout of
+ * fdbm_conv_args.stat_out with stat_G = nf/4) for the GroupNorms that read the stem's output;
+ * needs nf/8 to divide 256.  stat_out NULL = fdbm_conv_stem. */
+int fdbm_conv_stem_stats(void* out, const float* in, const float* w, const float* bias, int B, int H,
+                         int W, int nf, int dt_out, float* stat_out, int stat_nsplit, void* stream);
 
 /* ------------------------------------------------------------------ GroupNorm
  * nn.GroupNorm(min(C/4,32), C, eps=1e-6) (layerspp.py:67,219,231; ncsnpp_v2.py:205,217)

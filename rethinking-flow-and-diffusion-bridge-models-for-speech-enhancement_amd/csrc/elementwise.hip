@@ -359,24 +359,29 @@ template <typename T>
 __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
                                                         const f32x4* __restrict__ in,
                                                         const float* __restrict__ w,
-                                                        const float* __restrict__ bias, int B, int H,
-                                                        int W, int nf) {
-  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [36][nf] (k-major) + [nf] bias
+                                                        const float* __restrict__ bias, int H,
+                                                        int W, int nf, float* __restrict__ stat_out,
+                                                        int stat_nsplit) {
+  extern __shared__ __attribute__((aligned(16))) float s_w[];  // [36][nf] (k-major) + [nf] bias + [nf/4][2] statistics
+  float* s_st = s_w + nf * 37;
   for (int i = threadIdx.x; i < nf * 36; i += blockDim.x) {
     const int oc = i / 36, k = i % 36;
     s_w[k * nf + oc] = w[i];
   }
   for (int i = threadIdx.x; i < nf; i += blockDim.x) s_w[nf * 36 + i] = bias[i];
+  if (stat_out)
+    for (int i = threadIdx.x; i < nf / 2; i += blockDim.x) s_st[i] = 0.f;
   __syncthreads();
-  const int ncg = nf / 8;   // 8 output channels per thread
-  const int64_t total = (int64_t)B * H * W * ncg;
+  const int ncg = nf / 8;   // 8 output channels per thread; the grid stride is a multiple of ncg: cg is fixed per thread
+  const int64_t b = blockIdx.y;
+  const int64_t total = (int64_t)H * W * ncg;
+  float u1[2] = {0.f, 0.f}, u2[2] = {0.f, 0.f};     // (sum, sumsq) of this thread's two 4-channel units
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
   const int cg = (int)(idx % ncg);
   const int64_t p = idx / ncg;
   const int x = (int)(p % W);
-  const int y = (int)((p / W) % H);
-  const int64_t b = p / ((int64_t)W * H);
+  const int y = (int)(p / W);
   float tap[36];
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky)
@@ -404,29 +409,61 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] += s_w[nf * 36 + cg * 8 + j];
-  T* dst = out + p * nf + cg * 8;
+  T* dst = out + (b * H * W + p) * nf + cg * 8;
   if constexpr (sizeof(T) == 2) {
     Vec16<T>::store(dst, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (float)(bf16_t)o[j];       // statistics of the STORED tensor
   } else {
     Vec16<T>::store(dst, o);
     Vec16<T>::store(dst + 4, o + 4);
   }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    u1[h] += (o[4 * h] + o[4 * h + 1]) + (o[4 * h + 2] + o[4 * h + 3]);
+    u2[h] += (o[4 * h] * o[4 * h] + o[4 * h + 1] * o[4 * h + 1]) + (o[4 * h + 2] * o[4 * h + 2] + o[4 * h + 3] * o[4 * h + 3]);
+  }
+  }
+  if (stat_out) {
+    // unit statistics [B][stat_nsplit][nf/4][2] (fdbm_conv_args.stat_out layout with stat_G = nf/4)
+    const int cg = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) % ncg);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      atomicAdd(&s_st[(cg * 2 + h) * 2], u1[h]);
+      atomicAdd(&s_st[(cg * 2 + h) * 2 + 1], u2[h]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nf / 2; i += blockDim.x)
+      atomicAdd(stat_out + ((b * stat_nsplit + blockIdx.x % stat_nsplit) * (nf / 4)) * 2 + i, s_st[i]);
   }
 }
 
 extern "C" int fdbm_conv_stem(void* out, const float* in, const float* w, const float* bias, int B,
                               int H, int W, int nf, int dt_out, void* stream) {
+  return fdbm_conv_stem_stats(out, in, w, bias, B, H, W, nf, dt_out, nullptr, 0, stream);
+}
+
+extern "C" int fdbm_conv_stem_stats(void* out, const float* in, const float* w, const float* bias, int B,
+                                    int H, int W, int nf, int dt_out, float* stat_out, int stat_nsplit,
+                                    void* stream) {
   FDBM_CHECK(out && in && w && bias, "fdbm_conv_stem: null pointer");
-  FDBM_CHECK(nf % 8 == 0 && nf <= 256, "fdbm_conv_stem: nf=%d unsupported", nf);
-  const int64_t total = (int64_t)B * H * W * (nf / 8);
-  const size_t smem = (size_t)nf * 37 * sizeof(float);
+  FDBM_CHECK(nf % 8 == 0 && nf > 0 && nf <= 256, "fdbm_conv_stem: nf=%d must be a multiple of 8, <= 256", nf);
+  FDBM_CHECK(!stat_out || stat_nsplit >= 1, "fdbm_conv_stem: stat_nsplit must be >= 1");
   hipStream_t st = (hipStream_t)stream;
+  const size_t smem = (size_t)nf * 37 * sizeof(float) + (size_t)(nf / 2) * sizeof(float);
+  const int64_t total = (int64_t)H * W * (nf / 8);
   int gs = cdiv(total, 256);
-  if (gs > 1024) gs = 1024;            // grid-stride: the [36][nf] weight staging is paid 1024 times, not 4096
+  int cap = 1024 / (B < 1 ? 1 : B);     // grid-stride: the [36][nf] weight staging is paid ~1024 times, not 4096
+  if (cap < 64) cap = 64;
+  if (gs > cap) gs = cap;
+  // the stride gs * 256 must be a multiple of nf/8 (a thread keeps its channel group): 256 is, for nf <= 256... only
+  // when nf/8 divides 256
+  FDBM_CHECK(256 % (nf / 8) == 0 || !stat_out, "fdbm_conv_stem: statistics need nf/8 (%d) to divide 256", nf / 8);
+  dim3 grid(gs, B);
   if (dt_out == FDBM_BF16)
-    conv_stem_kernel<bf16_t><<<gs, 256, smem, st>>>((bf16_t*)out, (const f32x4*)in, w, bias, B, H, W, nf);
+    conv_stem_kernel<bf16_t><<<grid, 256, smem, st>>>((bf16_t*)out, (const f32x4*)in, w, bias, H, W, nf, stat_out, stat_nsplit);
   else if (dt_out == FDBM_F32)
-    conv_stem_kernel<float><<<gs, 256, smem, st>>>((float*)out, (const f32x4*)in, w, bias, B, H, W, nf);
+    conv_stem_kernel<float><<<grid, 256, smem, st>>>((float*)out, (const f32x4*)in, w, bias, H, W, nf, stat_out, stat_nsplit);
   else
     FDBM_CHECK(false, "fdbm_conv_stem: bad dtype %d", dt_out);
   FDBM_LAUNCH_CHECK("fdbm_conv_stem");

@@ -63,6 +63,7 @@ _SIGS = {
     "fdbm_temb": [c_void_p] * 8 + [c_int] * 2,
     "fdbm_dense_rows": [c_void_p] * 4 + [c_int] * 3,
     "fdbm_conv_stem": [c_void_p] * 4 + [c_int] * 5,
+    "fdbm_conv_stem_stats": [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_int],
     "fdbm_gn_stats": [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 5,
     "fdbm_gn_finalize": [c_void_p, c_void_p, c_int, c_int, c_int, c_i64, c_float],
     "fdbm_gn_apply": [c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_i64, c_float, c_void_p, c_void_p] + [c_int] * 5,

@@ -511,7 +511,15 @@ class Program:
         stem = nxt()
         h = self.new_act(Fn, T, nf)
         sw = net.w[stem.idx]
-        self.emit(hip.OP_STEM, [h.ptr, inp.ptr, sw["w"].data_ptr(), sw["b"].data_ptr(), B, Fn, T, nf, self.dtc])
+        stem_slot, stem_nsp = 0, 0
+        if self.fused and 256 % (nf // 8) == 0:
+            # the stem leaves the unit statistics of its output for the GroupNorms that read it (the first
+            # res-block and, over the skip connection, the last one)
+            stem_nsp = 16
+            stem_slot = self.new_slot(stem_nsp, nf // 4)
+            h.ustats = (stem_slot, stem_nsp)
+        self.emit(hip.OP_STEM, [h.ptr, inp.ptr, sw["w"].data_ptr(), sw["b"].data_ptr(), B, Fn, T, nf, self.dtc,
+                                stem_slot, stem_nsp])
         self.macs += Fn * T * nf * IN_CH * 9
         hs = [h]
         pyr_in = inp

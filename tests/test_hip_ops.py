@@ -472,6 +472,15 @@ def test_stem_pack_unpack_combine(dtype, tol):
     wd, bdv = w.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV)
     hip.call("fdbm_conv_stem", hip.ptr(out), hip.ptr(inp), hip.ptr(wd), hip.ptr(bdv), B, 256, T, nf, hip.dt_code(dtype))
     assert close(nchw(out), F.conv2d(ref_in, w, b, padding=1), tol)
+    # the same with the unit statistics (per image and 4 channels) of the stored output
+    out2 = torch.empty_like(out)
+    st = torch.zeros(B, 5, nf // 4, 2, device=DEV)
+    hip.call("fdbm_conv_stem_stats", hip.ptr(out2), hip.ptr(inp), hip.ptr(wd), hip.ptr(bdv), B, 256, T, nf, hip.dt_code(dtype),
+             hip.ptr(st), 5)
+    assert torch.equal(out2, out)
+    ou = out.float().cpu().reshape(B, 256 * T, nf // 4, 4)
+    ref_st = torch.stack([ou.sum((1, 3)), (ou * ou).sum((1, 3))], -1)
+    assert ((st.cpu().sum(1) - ref_st).abs() <= 1e-4 * (1 + ref_st.abs())).all()
     # output layer + Nyquist row
     pyr = rnd(B, 4, 256, T, seed=5)
     ow, ob = rnd(2, 4, seed=6), rnd(2, seed=7)

@@ -1,7 +1,7 @@
 // elementwise.hip - HBM-bound passes of the sampling path: sampler state update,
 // predictor / corrector moves, network input packing / output projection, Combine,
 // time embedding and the 4->nf stem convolution.  All fp32 math; 16-byte accesses.
-#include "common.h"
+#include "conv_common.h"
 
 // ---------------------------------------------------------------------------------
 // sampler state update: out = (wa*a + wb*b) + wc*c   (complex64 viewed as floats)
@@ -438,6 +438,87 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
   }
 }
 
+// Matrix-core stem (W % 16 == 0, nf = 16 NT): the 4 input channels of one tap are exactly the K = 4 of
+// v_mfma_f32_16x16x4_f32, so a 3x3 x 4-channel stem is 9 MFMA k-steps per (16 pixels x 16 channels) tile
+// in full fp32 (an exact fma chain - the parity mode uses it too).  A wave keeps its 9 x NT weight
+// operands in registers and walks over 16-pixel row segments; the input operand of a tap is one float
+// per lane (pixel = lane & 15, channel = lane >> 4), read straight from the packed NHWC4 input.
+template <typename T, int NT>
+__global__ void __launch_bounds__(256) conv_stem_mfma_kernel(T* __restrict__ out, const float* __restrict__ in,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ bias, int H, int W,
+                                                             float* __restrict__ stat_out, int stat_nsplit,
+                                                             int tiles_per_wave) {
+  constexpr int nf = 16 * NT;
+  __shared__ float s_w[nf * 36 + nf];
+  __shared__ float s_st[nf / 2];
+  for (int i = threadIdx.x; i < nf * 36; i += 256) s_w[i] = w[i];
+  for (int i = threadIdx.x; i < nf; i += 256) s_w[nf * 36 + i] = bias[i];
+  if (threadIdx.x < nf / 2) s_st[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int frow = lane & 15, fk = lane >> 4;
+  float wf[NT][9];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wf[j][t] = s_w[(j * 16 + frow) * 36 + t * 4 + fk];
+  f32x4 bv[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) bv[j] = *reinterpret_cast<const f32x4*>(s_w + nf * 36 + j * 16 + fk * 4);
+  const int b = blockIdx.y;
+  const int tiles_x = W / 16;
+  const int ntiles = H * tiles_x;
+  const float* img = in + (int64_t)b * H * W * 4;
+  float u1[NT], u2[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) u1[j] = u2[j] = 0.f;
+  const int t0 = (blockIdx.x * 4 + wave) * tiles_per_wave;
+  for (int t = t0; t < min(ntiles, t0 + tiles_per_wave); ++t) {
+    const int y = t / tiles_x, x = (t - y * tiles_x) * 16 + frow;
+    float v[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+      const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      const float q = img[((int64_t)min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1)) * 4 + fk];
+      v[tap] = ok ? q : 0.f;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][tap], v[tap], acc[j], 0, 0, 0);
+    T* dst = out + (((int64_t)b * H + y) * W + x) * nf + fk * 4;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float o[4] = {acc[j][0] + bv[j][0], acc[j][1] + bv[j][1], acc[j][2] + bv[j][2], acc[j][3] + bv[j][3]};
+      OutVec<T>::store(dst + j * 16, o);
+      if constexpr (sizeof(T) == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (float)(bf16_t)o[r];       // statistics of the STORED tensor
+      }
+      u1[j] += (o[0] + o[1]) + (o[2] + o[3]);
+      u2[j] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+    }
+  }
+  if (stat_out) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const float r1 = row16_sum(u1[j]), r2 = row16_sum(u2[j]);     // over the 16 pixels of the tile row
+      if (frow == 0) {
+        atomicAdd(&s_st[(j * 4 + fk) * 2], r1);
+        atomicAdd(&s_st[(j * 4 + fk) * 2 + 1], r2);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < nf / 2)
+      atomicAdd(stat_out + (((int64_t)b * stat_nsplit + blockIdx.x % stat_nsplit) * (nf / 4)) * 2 + threadIdx.x, s_st[threadIdx.x]);
+  }
+}
+
 extern "C" int fdbm_conv_stem(void* out, const float* in, const float* w, const float* bias, int B,
                               int H, int W, int nf, int dt_out, void* stream) {
   return fdbm_conv_stem_stats(out, in, w, bias, B, H, W, nf, dt_out, nullptr, 0, stream);
@@ -450,6 +531,21 @@ extern "C" int fdbm_conv_stem_stats(void* out, const float* in, const float* w, 
   FDBM_CHECK(nf % 8 == 0 && nf > 0 && nf <= 256, "fdbm_conv_stem: nf=%d must be a multiple of 8, <= 256", nf);
   FDBM_CHECK(!stat_out || stat_nsplit >= 1, "fdbm_conv_stem: stat_nsplit must be >= 1");
   hipStream_t st = (hipStream_t)stream;
+  if (W % 16 == 0 && (nf == 32 || nf == 64 || nf == 96 || nf == 128)) {     // matrix-core variant
+    const int ntiles = H * (W / 16);
+    int tpw = 4;                                                  // 16-pixel tiles per wave (weights loaded once per wave)
+    while (tpw < 64 && (int64_t)B * cdiv(ntiles, 4 * tpw) > 2048) tpw *= 2;
+    dim3 grid(cdiv(ntiles, 4 * tpw), B);
+#define STEM_MFMA(TT, NTT) conv_stem_mfma_kernel<TT, NTT><<<grid, 256, 0, st>>>((TT*)out, in, w, bias, H, W, stat_out, stat_nsplit, tpw)
+#define STEM_NT(TT) do { if (nf == 128) STEM_MFMA(TT, 8); else if (nf == 96) STEM_MFMA(TT, 6); else if (nf == 64) STEM_MFMA(TT, 4); else STEM_MFMA(TT, 2); } while (0)
+    if (dt_out == FDBM_BF16) STEM_NT(bf16_t);
+    else if (dt_out == FDBM_F32) STEM_NT(float);
+    else FDBM_CHECK(false, "fdbm_conv_stem: bad dtype %d", dt_out);
+#undef STEM_NT
+#undef STEM_MFMA
+    FDBM_LAUNCH_CHECK("fdbm_conv_stem(mfma)");
+    return 0;
+  }
   const size_t smem = (size_t)nf * 37 * sizeof(float) + (size_t)(nf / 2) * sizeof(float);
   const int64_t total = (int64_t)H * W * (nf / 8);
   int gs = cdiv(total, 256);

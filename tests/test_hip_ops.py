@@ -458,9 +458,10 @@ def test_temb_and_dense():
     assert (o2.cpu() - F.linear(out.cpu(), wd, bd)).abs().max() < 1e-5
 
 
+@pytest.mark.parametrize("T,nf", [(16, 64), (32, 128), (24, 64)], ids=["mfma_nf64", "mfma_nf128", "valu_w24"])
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 8e-3)])
-def test_stem_pack_unpack_combine(dtype, tol):
-    B, Fq, T, nf = 2, 257, 16, 64
+def test_stem_pack_unpack_combine(dtype, tol, T, nf):
+    B, Fq = 2, 257
     x, y = crnd(B, 1, Fq, T, seed=1), crnd(B, 1, Fq, T, seed=2)
     inp = torch.empty(B, 256, T, 4, device=DEV)
     xd, yd = x.to(DEV), y.to(DEV)
@@ -489,7 +490,7 @@ def test_stem_pack_unpack_combine(dtype, tol):
     hip.call("fdbm_unpack_output", hip.ptr(s), hip.ptr(pd), hip.ptr(owd), hip.ptr(obd), B, Fq, 256, T)
     r = F.conv2d(pyr, ow[:, :, None, None], ob)
     ref = torch.cat((torch.complex(r[:, 0], r[:, 1])[:, None], torch.zeros(B, 1, 1, T, dtype=torch.complex64)), 2)
-    assert (s.cpu() - ref).abs().max() < 1e-6
+    assert (s.cpu() - ref).abs().max() < 3e-6
     # Combine
     C = 64
     h, p = rnd(B, C, 8, 8, seed=8), rnd(B, 4, 8, 8, seed=9)

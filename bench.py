@@ -244,19 +244,31 @@ def main():
     f_dom = sum(flops[i] for i in sel)
     achieved = f_dom / t_dom / 1e12
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "c_pmc_traffic_b1_bf16.json")
+    pmc = os.path.join(ROOT, "profiles", "r01", "e_pmc_traffic_b1_bf16.json")
     if args.batch == 1 and args.dtype == "bf16" and os.path.exists(pmc):
         try:        # measured offline with rocprofv3 --pmc (tools/pmc_workload.py), bytes per launch
             traffic = json.load(open(pmc))["conv_patch_kernel"]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
     t_conv = sum(times) * 1e-3
+    fam_name = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel"}
+    families = {}
+    for kind, name in fam_name.items():
+        ids = [i for i, k in enumerate(kinds) if k == kind]
+        if ids:
+            tt, ff = sum(times[i] for i in ids) * 1e-3, sum(flops[i] for i in ids)
+            families[name] = {"launches_per_forward": len(ids), "ms_per_forward": 1e3 * tt,
+                              "achieved": ff / tt / 1e12, "frac": ff / tt / 1e12 / peak,
+                              "share_of_forward_flops": ff / sum(flops), "share_of_conv_time": tt / t_conv}
     result["roofline"] = {
         "bound": "mfma", "kernel": "conv_patch_kernel" if any(k == 1 for k in kinds) else "conv_igemm_kernel",
         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
         "launches_per_forward": len(sel), "avg_launch_us": 1e6 * t_dom / len(sel),
         "algorithmic_gflop_per_launch_avg": f_dom / len(sel) / 1e9,
         "share_of_forward_flops": f_dom / sum(flops),
+        # every convolution kernel family of the forward (HIP-event time of its launches, eager replay):
+        # conv_patch carries most of the flops, the latency-bound small-map kernel most of the batch-1 time
+        "families": families,
         "all_conv": {"achieved": sum(flops) / t_conv / 1e12, "frac": sum(flops) / t_conv / 1e12 / peak,
                      "launches_per_forward": len(times), "ms_per_forward": 1e3 * t_conv},
         "forward_ms_eager": fwd_ms, "forward_ms_in_graph": 1e3 * elapsed / args.steps / args.N,

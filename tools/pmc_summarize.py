@@ -6,8 +6,12 @@ for name, d in (("FETCH_SIZE", sys.argv[1]), ("WRITE_SIZE", sys.argv[2])):
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        fam = "conv_patch_kernel" if "conv_patch_kernel" in k else "conv_igemm_kernel" if "conv_igemm_kernel" in k else \
-              "gn_stats_kernel" if "gn_stats" in k else "gn_apply_kernel" if "gn_apply" in k else "resample2x_kernel" if "resample2x" in k else None
+        fam = None
+        for f_ in ("conv_patch_kernel", "conv_tap_kernel", "conv_igemm_kernel", "conv_stem_mfma_kernel", "attention_mfma_kernel",
+                   "resample2x_tile_kernel", "resample2x_kernel", "gn_stats_kernel", "gn_apply_kernel"):
+            if f_ in k:
+                fam = f_
+                break
         if fam and r["Counter_Name"] == name:
             acc[fam].append(float(r["Counter_Value"]))
     for fam, v in acc.items():

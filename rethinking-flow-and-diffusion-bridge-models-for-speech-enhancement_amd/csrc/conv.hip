@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
   }
 
   // ---- GroupNorm prologue table + output-statistics scratch (after the two LDS buffers) ----
-  float2* s_gn = reinterpret_cast<float2*>(smem + KG * 2 * BUF);             // [nb][gn_C] {scale, shift}
+  float* s_gn = reinterpret_cast<float*>(smem + KG * 2 * BUF);               // scale[nb][gn_C] | shift[nb][gn_C] (second half)
   float* s_stat = reinterpret_cast<float*>(smem + KG * 2 * BUF + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0));  // [nb][32][2]
   const int b0 = (int)(m0 / HW);
   int pbl[AROWS];
@@ -158,28 +158,8 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
       if constexpr (GNP) {
         const int cb = (S == 0 ? gcb0 : gcb1);
         if (cb >= 0) {             // wave-uniform per k-step (a property of the segment)
-          const float2* tab = s_gn + pbl[i] * p.gn_C + cb;
-          if constexpr (sizeof(T) == 2) {
-            bf16x8 e = *reinterpret_cast<bf16x8*>(&v);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-              const float2 ss = tab[q];
-              float y = (float)e[q] * ss.x + ss.y;
-              if (p.gn_silu) y = silu_f(y);
-              e[q] = (bf16_t)y;
-            }
-            v = *reinterpret_cast<uint4*>(&e);
-          } else {
-            f32x4 e = *reinterpret_cast<f32x4*>(&v);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float2 ss = tab[q];
-              float y = e[q] * ss.x + ss.y;
-              if (p.gn_silu) y = silu_precise(y);
-              e[q] = y;
-            }
-            v = *reinterpret_cast<uint4*>(&e);
-          }
+          const float* tsc = s_gn + pbl[i] * p.gn_C + cb;
+          v = gn_transform16<T>(v, tsc, tsc + CONV_MAX_NB * CONV_GN_MAXC, p.gn_silu != 0);
         }
       }
       if (!((okm >> i) & 1u)) v = uint4{0u, 0u, 0u, 0u};     // zero padding AFTER the activation
@@ -271,7 +251,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
       const int64_t mlast = min(M, m0 + BM) - 1;
       const int nb = (int)(mlast / HW) - b0 + 1;
       // (scratch: the LDS tile buffers, not written before the barrier that follows)
-      conv_gn_table<NTHR>(p, b0, nb, s_gn, s_stat + CONV_MAX_NB * 64, smem);
+      conv_gn_table<NTHR>(p, b0, nb, s_gn, CONV_MAX_NB * CONV_GN_MAXC, s_stat + CONV_MAX_NB * 64, smem);
     }
   };
 

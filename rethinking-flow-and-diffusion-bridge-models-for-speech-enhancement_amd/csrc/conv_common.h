@@ -123,14 +123,16 @@ __device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int64_t m, i
   }
 }
 
-// GroupNorm prologue table: per (image of this workgroup, channel) {scale, shift} from the partial
-// (sum, sumsq) rows the producer left: s_gn[bl * gn_C + c] = {rstd * gamma, beta - mean * rstd * gamma}.
+// GroupNorm prologue table: per (image of this workgroup, channel) scale and shift from the partial
+// (sum, sumsq) rows the producer left, as TWO arrays (scale at s_gn[i], shift at s_gn[shoff + i],
+// i = bl * gn_C + c; adjacent channels adjacent, so that the transform runs on packed-f32 instructions):
+// scale = rstd * gamma, shift = beta - mean * rstd * gamma.
 // The |gn_nsplit| partial rows of an (image, group) are dealt out over NTHR / (32 nb) threads (a single
 // thread walking 16-64 rows one load after the other costs 5-20 us of pure latency), the partials are
 // summed in fp64 in a fixed order.  `scratch` is any LDS the kernel is not using yet
 // (>= NTHR * 16 bytes), s_mr holds [nb][32][2] floats.  Ends with a barrier.
 template <int NTHR>
-__device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int nb, float2* s_gn, float* s_mr,
+__device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int nb, float* s_gn, int shoff, float* s_mr,
                                               unsigned char* scratch) {
   const int tid = threadIdx.x;
   const int G = p.gn_G, C = p.gn_C;
@@ -197,9 +199,39 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
     const int ib = i / C, c = i - ib * C;
     const int gg = c / cpg;
     const float sc = s_mr[2 * (ib * 32 + gg) + 1] * p.gn_gamma[c];
-    s_gn[i] = float2{sc, p.gn_beta[c] - s_mr[2 * (ib * 32 + gg)] * sc};
+    s_gn[i] = sc;
+    s_gn[shoff + i] = p.gn_beta[c] - s_mr[2 * (ib * 32 + gg)] * sc;
   }
   __syncthreads();
+}
+
+// GroupNorm scale/shift (+ SiLU) of one 16-byte vector of activations (8 bf16 / 4 f32) whose first
+// channel's table entries are tsc[0] / tsh[0].
+template <typename T>
+__device__ __forceinline__ uint4 gn_transform16(uint4 v, const float* tsc, const float* tsh, bool silu) {
+  if constexpr (sizeof(T) == 2) {
+    bf16x8 e = *reinterpret_cast<bf16x8*>(&v);
+    float y[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[q] = (float)e[q] * tsc[q] + tsh[q];
+    if (silu) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) y[q] = silu_f(y[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) e[q] = (bf16_t)y[q];
+    return *reinterpret_cast<uint4*>(&e);
+  } else {
+    f32x4 e = *reinterpret_cast<f32x4*>(&v);
+    if (silu) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = silu_precise(e[q] * tsc[q] + tsh[q]);
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) e[q] = e[q] * tsc[q] + tsh[q];
+    }
+    return *reinterpret_cast<uint4*>(&e);
+  }
 }
 
 // p.seg[ks] with a run-time ks makes the compiler copy the whole kernel argument to scratch

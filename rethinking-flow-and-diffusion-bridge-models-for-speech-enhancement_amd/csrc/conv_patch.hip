@@ -38,7 +38,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_patch = smem;                          // 2 x PBUF
   unsigned char* s_w = smem + 2 * PBUF;                   // 2 x WBUF
-  float2* s_gn = reinterpret_cast<float2*>(smem + 2 * PBUF + 2 * WBUF);                       // [gn_C]
+  float* s_gn = reinterpret_cast<float*>(smem + 2 * PBUF + 2 * WBUF);                         // scale[gnpad] | shift[gnpad]
   float* s_stat = reinterpret_cast<float*>(smem + 2 * PBUF + 2 * WBUF + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0));  // [32][2] + [32][2] (after the table)
 
   const int tid = threadIdx.x;
@@ -77,7 +77,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   auto build_gn_table = [&]() __attribute__((always_inline)) {
     // (scratch: the second patch buffer, idle until the first chunk's taps; the first weight tile is
     // being written to s_w meanwhile)
-    if constexpr (GNP) conv_gn_table<NTHR>(p, b, 1, s_gn, s_stat + 64, s_patch + PBUF);
+    if constexpr (GNP) conv_gn_table<NTHR>(p, b, 1, s_gn, (p.gn_C + 63) & ~63, s_stat + 64, s_patch + PBUF);
   };
 
   // ---- chunk cursor -------------------------------------------------------------------------------
@@ -110,30 +110,8 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
       unsigned char* P = s_patch + buf * PBUF;
       uint4 v = preg[j];
       if constexpr (GNP) {
-        if (pgcb >= 0) {                   // wave-uniform: a property of the segment
-          const float2* tab = s_gn + pgcb;
-          if constexpr (!F32) {
-            bf16x8 e = *reinterpret_cast<bf16x8*>(&v);
-            if (p.gn_silu) {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) { const float2 ss = tab[q]; e[q] = (bf16_t)silu_f((float)e[q] * ss.x + ss.y); }
-            } else {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) { const float2 ss = tab[q]; e[q] = (bf16_t)((float)e[q] * ss.x + ss.y); }
-            }
-            v = *reinterpret_cast<uint4*>(&e);
-          } else {
-            f32x4 e = *reinterpret_cast<f32x4*>(&v);
-            if (p.gn_silu) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { const float2 ss = tab[q]; e[q] = silu_precise(e[q] * ss.x + ss.y); }
-            } else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { const float2 ss = tab[q]; e[q] = e[q] * ss.x + ss.y; }
-            }
-            v = *reinterpret_cast<uint4*>(&e);
-          }
-        }
+        if (pgcb >= 0)                     // wave-uniform: a property of the segment
+          v = gn_transform16<T>(v, s_gn + pgcb, s_gn + ((p.gn_C + 63) & ~63) + pgcb, p.gn_silu != 0);
       }
       if (!(((pmask >> j) & 1u) && pcok)) v = uint4{0u, 0u, 0u, 0u};   // padding AFTER the activation
       if (plds[j] >= 0) *reinterpret_cast<uint4*>(P + plds[j]) = v;

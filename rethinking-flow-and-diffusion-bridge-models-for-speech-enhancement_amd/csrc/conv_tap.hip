@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_patch = smem;                                         // 2 x PBUF (slabs alias it later)
-  float2* s_gn = reinterpret_cast<float2*>(smem + MAIN);                 // [gn_C] {scale, shift}
+  float* s_gn = reinterpret_cast<float*>(smem + MAIN);                   // scale[CONV_GN_MAXC] | shift[CONV_GN_MAXC]
   float* s_stat = reinterpret_cast<float*>(smem + MAIN + (GNP ? CONV_GN_MAXC * 8 : 0));   // [32][2] + [32][2]
 
   const int tid = threadIdx.x;
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
     for (int i = tid; i < 64; i += TAP_NTHR) s_stat[i] = 0.f;
 
   auto build_gn_table = [&]() __attribute__((always_inline)) {
-    if constexpr (GNP) conv_gn_table<TAP_NTHR>(p, b, 1, s_gn, s_stat + 64, smem);   // (the patch buffers are still idle)
+    if constexpr (GNP) conv_gn_table<TAP_NTHR>(p, b, 1, s_gn, CONV_GN_MAXC, s_stat + 64, smem);   // (the patch buffers are still idle)
   };
 
   auto seg_nch = [&](int s) __attribute__((always_inline)) { return (SEG_FIELD(p, s, cin) + KC - 1) / KC; };
@@ -145,30 +145,8 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
       uint4 v;
       if constexpr (S == 0) v = pregA[j]; else v = pregB[j];
       if constexpr (GNP) {
-        if (pgcb >= 0) {                   // wave-uniform: a property of the segment
-          const float2* tab = s_gn + pgcb;
-          if constexpr (!F32) {
-            bf16x8 e = *reinterpret_cast<bf16x8*>(&v);
-            if (p.gn_silu) {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) { const float2 ss = tab[q]; e[q] = (bf16_t)silu_f((float)e[q] * ss.x + ss.y); }
-            } else {
-#pragma unroll
-              for (int q = 0; q < 8; ++q) { const float2 ss = tab[q]; e[q] = (bf16_t)((float)e[q] * ss.x + ss.y); }
-            }
-            v = *reinterpret_cast<uint4*>(&e);
-          } else {
-            f32x4 e = *reinterpret_cast<f32x4*>(&v);
-            if (p.gn_silu) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { const float2 ss = tab[q]; e[q] = silu_precise(e[q] * ss.x + ss.y); }
-            } else {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) { const float2 ss = tab[q]; e[q] = e[q] * ss.x + ss.y; }
-            }
-            v = *reinterpret_cast<uint4*>(&e);
-          }
-        }
+        if (pgcb >= 0)                     // wave-uniform: a property of the segment
+          v = gn_transform16<T>(v, s_gn + pgcb, s_gn + CONV_GN_MAXC + pgcb, p.gn_silu != 0);
       }
       if (!(((pmask >> j) & 1u) && pcok)) v = uint4{0u, 0u, 0u, 0u};   // padding AFTER the activation
       if (plds[j] >= 0) *reinterpret_cast<uint4*>(P + plds[j]) = v;

@@ -142,6 +142,10 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
   const int bl = slot >> 5, g = slot & 31;
   double* red = reinterpret_cast<double*>(scratch);
   const int nsp = p.gn_nsplit < 0 ? -p.gn_nsplit : p.gn_nsplit;
+  // gamma / beta of this thread's first two table entries: requested now, beside the statistics rows,
+  // instead of after the two barriers below (one exposed memory round trip less per launch)
+  const int ce0 = tid % C, ce1 = (tid + NTHR) % C;
+  const float g0 = p.gn_gamma[ce0], be0 = p.gn_beta[ce0], g1 = p.gn_gamma[ce1], be1 = p.gn_beta[ce1];
   double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
   if (g < G && part < nparts && p.gn_unit) {
     // units of 4 channels, one buffer per segment: group g = units [g * upg, (g + 1) * upg)
@@ -195,12 +199,14 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
   }
   __syncthreads();
   const int cpg = C / G;
-  for (int i = tid; i < nb * C; i += NTHR) {
+  for (int i = tid, it = 0; i < nb * C; i += NTHR, ++it) {
     const int ib = i / C, c = i - ib * C;
     const int gg = c / cpg;
-    const float sc = s_mr[2 * (ib * 32 + gg) + 1] * p.gn_gamma[c];
+    const float ga = it == 0 ? g0 : it == 1 ? g1 : p.gn_gamma[c];
+    const float be = it == 0 ? be0 : it == 1 ? be1 : p.gn_beta[c];
+    const float sc = s_mr[2 * (ib * 32 + gg) + 1] * ga;
     s_gn[i] = sc;
-    s_gn[shoff + i] = p.gn_beta[c] - s_mr[2 * (ib * 32 + gg)] * sc;
+    s_gn[shoff + i] = be - s_mr[2 * (ib * 32 + gg)] * sc;
   }
   __syncthreads();
 }

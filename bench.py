@@ -86,7 +86,7 @@ def time_conv_launches(net, B, F, T, reps=3):
     prog = net.program(B, F, T)
     prog.run()
     torch.cuda.synchronize()
-    conv_ids = [i for i, (opc, _, _) in enumerate(prog.ops) if opc == hip.OP_CONV]
+    conv_ids = [i for i, op in enumerate(prog.ops) if op[0] == hip.OP_CONV]
     best = [float("inf")] * len(conv_ids)
     fwd_ms = float("inf")
     for _ in range(reps):

@@ -272,7 +272,7 @@ int fdbm_pad_spec(void* out, const void* in, int64_t rows, int T, int Tpad, int 
  * (opcode + argument block per op) and replays it with one call (see fdbm_ncsnpp_forward). */
 typedef struct {
   int32_t opcode;        /* FDBM_OP_* */
-  int32_t reserved;
+  int32_t lane;          /* 0 = the caller's stream, 1 = the library's side stream (see FDBM_OP_FORK) */
   int64_t iarg[24];      /* integer / pointer arguments, meaning per opcode (program.cpp) */
   float farg[4];
 } fdbm_op;
@@ -291,6 +291,22 @@ typedef struct {
 #define FDBM_OP_DENSE 12
 #define FDBM_OP_UPDATE 13
 #define FDBM_OP_MEMSET 14      /* iarg: ptr, bytes (hipMemsetAsync to 0) */
+/* Off-critical-path chains (the 4-channel pyramids, the time-embedding MLP) may run on a side stream
+ * beside the main chain; the dependencies are explicit ops, all capturable into a HIP graph:
+ *   FORK e : everything enqueued so far on the caller's stream happens before the side-lane ops that follow
+ *   MARK e : (side lane) a point in the side stream ...
+ *   JOIN e : ... that the caller's stream waits for before going on.
+ * Unless fdbm_runtime_init_side() has created the side stream (it does so only with FDBM_SIDE_STREAM=1 in
+ * the environment: inside a HIP graph the cross-stream edges measured slower than what they save), every op
+ * runs on the caller's stream in program order and these three are no-ops - the results are identical. */
+#define FDBM_OP_FORK 15        /* iarg: event id */
+#define FDBM_OP_MARK 16        /* iarg: event id */
+#define FDBM_OP_JOIN 17        /* iarg: event id */
+#define FDBM_MAX_EVENTS 64
+
+/* creates the side stream and FDBM_MAX_EVENTS events once per process (call it outside graph capture;
+ * the only objects the library ever creates) */
+int fdbm_runtime_init_side(void);
 
 int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream);
 int fdbm_run_program(const fdbm_op* ops_host, int n_ops, void* stream);

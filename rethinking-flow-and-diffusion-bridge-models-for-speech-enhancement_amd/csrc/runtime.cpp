@@ -1,5 +1,6 @@
 // runtime.cpp - error reporting and the recorded-program runner.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -22,6 +23,27 @@ extern "C" int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream) {
   return 0;
 }
 
+// ---- side lane -------------------------------------------------------------------------------------
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev[FDBM_MAX_EVENTS];
+static bool g_side_ok = false;
+
+extern "C" int fdbm_runtime_init_side(void) {
+  if (g_side_ok) return 0;
+  // Opt-in (FDBM_SIDE_STREAM=1): measured on MI355X, the cross-stream edges cost more inside the HIP graph
+  // (14 per forward) than the ~120 us of work they take off the main chain: 3.35 ms vs 3.17 ms per forward.
+  const char* on = getenv("FDBM_SIDE_STREAM");
+  if (!(on && on[0] == '1')) return 0;
+  hipError_t e = hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking);
+  FDBM_CHECK(e == hipSuccess, "fdbm_runtime_init_side: hipStreamCreate failed: %s", hipGetErrorString(e));
+  for (int i = 0; i < FDBM_MAX_EVENTS; ++i) {
+    e = hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming);
+    FDBM_CHECK(e == hipSuccess, "fdbm_runtime_init_side: hipEventCreate failed: %s", hipGetErrorString(e));
+  }
+  g_side_ok = true;
+  return 0;
+}
+
 #define P(i) ((void*)(intptr_t)o.iarg[i])
 #define CP(i) ((const void*)(intptr_t)o.iarg[i])
 #define FP(i) ((float*)(intptr_t)o.iarg[i])
@@ -30,11 +52,30 @@ extern "C" int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream) {
 
 // Argument order per opcode = the parameter order of the C entry point (pointers and
 // integers in iarg[], floats in farg[]), minus the trailing stream.
-extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* stream) {
+extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* main_stream) {
   for (int k = 0; k < n_ops; ++k) {
     const fdbm_op& o = ops[k];
     int rc = 0;
+    void* stream = (o.lane == 1 && g_side_ok) ? (void*)g_side : main_stream;
     switch (o.opcode) {
+      case FDBM_OP_FORK:
+      case FDBM_OP_MARK:
+      case FDBM_OP_JOIN: {
+        if (!g_side_ok) break;
+        const int ev = I(0);
+        FDBM_CHECK(ev >= 0 && ev < FDBM_MAX_EVENTS, "fdbm_run_program: event id %d out of range at op %d", ev, k);
+        hipError_t e;
+        if (o.opcode == FDBM_OP_FORK) {
+          e = hipEventRecord(g_ev[ev], (hipStream_t)main_stream);
+          if (e == hipSuccess) e = hipStreamWaitEvent(g_side, g_ev[ev], 0);
+        } else if (o.opcode == FDBM_OP_MARK) {
+          e = hipEventRecord(g_ev[ev], g_side);
+        } else {
+          e = hipStreamWaitEvent((hipStream_t)main_stream, g_ev[ev], 0);
+        }
+        FDBM_CHECK(e == hipSuccess, "fdbm_run_program: stream dependency failed at op %d: %s", k, hipGetErrorString(e));
+        break;
+      }
       case FDBM_OP_CONV:
         rc = fdbm_conv_igemm((const fdbm_conv_args*)CP(0), stream);
         break;

@@ -46,12 +46,12 @@ class ConvArgs(ctypes.Structure):
 
 
 class Op(ctypes.Structure):
-    _fields_ = [("opcode", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    _fields_ = [("opcode", ctypes.c_int32), ("lane", ctypes.c_int32),
                 ("iarg", c_i64 * 24), ("farg", c_float * 4)]
 
 
 OP_CONV, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_RESAMPLE, OP_COMBINE, OP_ATTENTION, \
-    OP_STEM, OP_PACK, OP_UNPACK, OP_TEMB, OP_DENSE, OP_UPDATE, OP_MEMSET = range(1, 15)
+    OP_STEM, OP_PACK, OP_UNPACK, OP_TEMB, OP_DENSE, OP_UPDATE, OP_MEMSET, OP_FORK, OP_MARK, OP_JOIN = range(1, 18)
 
 # name -> (argtypes without the trailing stream)
 _SIGS = {
@@ -81,7 +81,7 @@ _SIGS = {
     "fdbm_run_program": [ctypes.POINTER(Op), c_int],
 }
 EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan",
-                                "fdbm_conv_plan_ex", "fdbm_conv_policy", "fdbm_ncsnpp_create", "fdbm_ncsnpp_destroy",
+                                "fdbm_conv_plan_ex", "fdbm_conv_policy", "fdbm_runtime_init_side", "fdbm_ncsnpp_create", "fdbm_ncsnpp_destroy",
                                 "fdbm_ncsnpp_forward"])
 
 
@@ -107,6 +107,8 @@ def lib():
         L.fdbm_conv_plan.restype = c_int
         L.fdbm_conv_plan_ex.argtypes = [c_int] * 6 + [ctypes.POINTER(c_int)] * 5
         L.fdbm_conv_plan_ex.restype = c_int
+        L.fdbm_runtime_init_side.argtypes = []
+        L.fdbm_runtime_init_side.restype = c_int
         L.fdbm_conv_policy.argtypes = [c_int]
         L.fdbm_conv_policy.restype = c_int
         L.fdbm_ncsnpp_create.argtypes = [ctypes.POINTER(Op), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int]

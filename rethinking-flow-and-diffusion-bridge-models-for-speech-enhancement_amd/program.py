@@ -172,11 +172,13 @@ class Program:
         self.dtc = hip.dt_code(net.dtype)
         self.esize = 2 if net.dtype == torch.bfloat16 else 4
         self.pool = Pool(self.dev)
-        self.ops = []          # (opcode, iargs, fargs)
+        self.ops = []          # (opcode, iargs, fargs, lane)
         self.keep = []         # tensors that must outlive the program
         self.keep_conv = []    # ConvArgs structs, one per conv op, in op order
         self.splitk_ws = None
         self.acc_ws = None
+        self.lane = 0
+        self.n_events = 0
         self.fused = net.fused
         # (sum, sumsq) slots [slot][B][32][2] that conv epilogues accumulate into with atomics;
         # zeroed by ONE memset at the head of every forward
@@ -206,8 +208,29 @@ class Program:
         return self.pool.get(n * 4)
 
     # ---- op recording ------------------------------------------------------------------
-    def emit(self, opcode, iargs, fargs=()):
-        self.ops.append((opcode, [int(v) for v in iargs], [float(v) for v in fargs]))
+    def emit(self, opcode, iargs, fargs=(), lane=None):
+        """lane 1 = the library's side stream (ops between fork() and the mark() their consumers join())."""
+        lane = self.lane if lane is None else lane
+        self.ops.append((opcode, [int(v) for v in iargs], [float(v) for v in fargs], lane))
+
+    # explicit dependencies between the caller's stream and the side stream (include/fdbm_hip.h, FDBM_OP_FORK)
+    def new_event(self):
+        self.n_events += 1
+        assert self.n_events <= 64
+        return self.n_events - 1
+
+    def fork(self):
+        """Side-lane ops emitted after this see everything emitted so far."""
+        self.emit(hip.OP_FORK, [self.new_event()], lane=0)
+
+    def mark(self):
+        """-> event: the point of the side stream a later join() waits for."""
+        ev = self.new_event()
+        self.emit(hip.OP_MARK, [ev], lane=1)
+        return ev
+
+    def join(self, ev):
+        self.emit(hip.OP_JOIN, [ev], lane=0)
 
     def stats_for(self, srcs, G, units_ok=True):
         """Statistics of GroupNorm(G) over cat(srcs) -> (descriptor, owned).  descriptor is
@@ -497,17 +520,32 @@ class Program:
         self.temb_act = self.new_f32(B * 4 * nf)
         temb_scratch = self.new_f32(B * 4 * nf)
         self.dense_out = self.new_f32(B * net.dense_rows)
+        # (side lane: the time-embedding chain and the input pyramid do not depend on the main chain; they run
+        # beside pack / stem / the first level and are joined where their first consumer is)
+        self.fork()
+        self.lane = 1
         self.emit(hip.OP_TEMB, [self.temb_act.data_ptr(), self.t_in.data_ptr(), net.fourier_w.data_ptr(),
                                 net.lin1_w.data_ptr(), net.lin1_b.data_ptr(), net.lin2_w.data_ptr(),
                                 net.lin2_b.data_ptr(), temb_scratch.data_ptr(), B, nf])
         self.emit(hip.OP_DENSE, [self.dense_out.data_ptr(), self.temb_act.data_ptr(), net.dense_w.data_ptr(),
                                  net.dense_b.data_ptr(), B, net.dense_rows, 4 * nf])
+        ev_dense = self.mark()
+        self.lane = 0
         self.macs += 2 * nf * 4 * nf + 4 * nf * 4 * nf + net.dense_rows * 4 * nf
 
         # input packing + stem
         inp = self.new_act(Fn, T, IN_CH, torch.float32)
         self.op_pack = len(self.ops)
         self.emit(hip.OP_PACK, [inp.ptr, self.x_in.data_ptr(), self.y_in.data_ptr(), B, F, Fn, T])
+        # the whole input pyramid (progressive input, ncsnpp_v2.py:296-305) on the side lane
+        self.fork()
+        self.lane = 1
+        pyr_levels = [inp]
+        for _ in range(spec.num_resolutions - 1):
+            pd_, _ = self.resample(pyr_levels[-1], False)
+            pyr_levels.append(pd_)
+        ev_pyr = self.mark()
+        self.lane = 0
         stem = nxt()
         h = self.new_act(Fn, T, nf)
         sw = net.w[stem.idx]
@@ -522,7 +560,7 @@ class Program:
                                 stem_slot, stem_nsp])
         self.macs += Fn * T * nf * IN_CH * 9
         hs = [h]
-        pyr_in = inp
+        self.join(ev_dense)                    # the res-blocks read their Dense_0 rows
 
         nres = spec.num_resolutions
         for lvl in range(nres):
@@ -535,18 +573,16 @@ class Program:
                 hs.append(h)
             if lvl != nres - 1:
                 down_mod, comb = nxt(), nxt()
-                pyr_down, _ = self.resample(pyr_in, False)
-                if pyr_in is not inp:
-                    self.free_act(pyr_in)
-                pyr_in = pyr_down
+                if lvl == 0:
+                    self.join(ev_pyr)
+                pyr_in = pyr_levels[lvl + 1]
                 cw = net.w[comb.idx]
                 # Combine('sum') rides in the epilogue of the down block's last conv
                 hd = self.resblock(down_mod, [hs[-1]], comb=(pyr_in, cw["w"], cw["b"]))
                 self.macs += hd.H * hd.W * IN_CH * hd.C
                 hs.append(hd)
-        if pyr_in is not inp:
-            self.free_act(pyr_in)
-        self.free_act(inp)
+        for pl_ in pyr_levels:
+            self.free_act(pl_)
 
         h = hs[-1]
         h2 = self.resblock(nxt(), [h])          # h stays alive: it is on the skip stack
@@ -557,6 +593,14 @@ class Program:
 
         pyramid = None
         for lvl in reversed(range(nres)):
+            # the previous level's output pyramid is upsampled on the side lane beside this level's res-blocks
+            up_pyr, ev_up = None, None
+            if pyramid is not None:
+                self.fork()
+                self.lane = 1
+                up_pyr, _ = self.resample(pyramid, True)
+                ev_up = self.mark()
+                self.lane = 0
             for _ in range(spec.num_res_blocks + 1):
                 skip = hs.pop()
                 hn = self.resblock(nxt(), [h, skip])
@@ -570,9 +614,8 @@ class Program:
             gnm, head = nxt(), nxt()
             G = gn_groups(h.C)
             gw, hw = net.w[gnm.idx], net.w[head.idx]
-            up_pyr = None
-            if pyramid is not None:
-                up_pyr, _ = self.resample(pyramid, True)
+            if ev_up is not None:
+                self.join(ev_up)
                 self.free_act(pyramid)
             segs = [(h, 0, h.C, 9)]
             a = None
@@ -607,8 +650,9 @@ class Program:
         self.ops[self.op_memset][1][1] = max(64, self.arena_used * 4)
         n = len(self.ops)
         arr = (hip.Op * n)()
-        for i, (opc, ia, fa) in enumerate(self.ops):
+        for i, (opc, ia, fa, lane) in enumerate(self.ops):
             arr[i].opcode = opc
+            arr[i].lane = lane
             for j, v in enumerate(ia):
                 arr[i].iarg[j] = v
             for j, v in enumerate(fa):
@@ -616,6 +660,8 @@ class Program:
         self.op_array = arr
         self.n_ops = n
         L = hip.lib()
+        if L.fdbm_runtime_init_side():
+            raise RuntimeError("fdbm_runtime_init_side failed: " + L.fdbm_last_error().decode())
         self.ctx = L.fdbm_ncsnpp_create(arr, n, self.x_in.data_ptr(), self.y_in.data_ptr(), self.t_in.data_ptr(),
                                         self.s_out.data_ptr(), self.x_in.numel(), self.B)
         if not self.ctx:

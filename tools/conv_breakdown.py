@@ -23,7 +23,7 @@ for _ in range(reps):
 tot = {}
 ci = 0
 print(f"{'op':12s} {'H':>4s} {'W':>4s} {'Cout':>5s} {'K':>6s} {'nk':>4s} {'blocks':>7s} {'us':>8s} {'TFLOP/s':>8s}")
-for i, (opc, ia, fa) in enumerate(prog.ops):
+for i, (opc, ia, fa, _lane) in enumerate(prog.ops):
     n = names[opc]
     tot[n] = tot.get(n, 0) + best[i]
     if opc == hip.OP_CONV:

@@ -65,6 +65,23 @@ def test_backbone_bf16_close(golden, name, fix):
     assert rel < 3e-2, rel                                  # bf16 storage, fp32 accumulate
 
 
+@pytest.mark.parametrize("name,Tn,B", [("ncsnpp_v2_16M", 64, 2), ("ncsnpp_v2_37M", 64, 1), ("ncsnpp_v2_5M", 320, 1),
+                                       ("ncsnpp_v2", 128, 1), ("ncsnpp_v2", 320, 1)])
+def test_registered_variants_bf16_vs_fp32(name, Tn, B):
+    """Every registered backbone, also on widths whose deeper levels do not tile by 16 (T = 320: the maps
+    fall back to the tap-outer kernel and to explicit statistics passes): the fused bf16 program against
+    the un-fused f32 program of the same weights."""
+    g = torch.Generator().manual_seed(7)
+    x = torch.view_as_complex(torch.randn(B, 1, 257, Tn, 2, generator=g)).to(DEV)
+    y = torch.view_as_complex(torch.randn(B, 1, 257, Tn, 2, generator=g)).to(DEV)
+    t = torch.full((B,), 0.37)
+    ref = net(name, torch.float32)(x, y, t.to(DEV)).cpu()
+    out = net(name, torch.bfloat16)(x, y, t.to(DEV)).cpu()
+    assert torch.isfinite(out.real).all() and torch.isfinite(out.imag).all()
+    rel = ((out - ref).abs().pow(2).sum() / ref.abs().pow(2).sum()).sqrt().item()
+    assert rel < 4e-2, (name, Tn, rel)
+
+
 SAMPLERS = [
     ("sb_bb_ode_ei_N5", dict(path="sb", noise_schedule="bb", N=5, sampler_type="ode_ei"), {}),
     ("fm_ot_ode_ei_N5", dict(path="fm", noise_schedule="ot", N=5, sampler_type="ode_ei"), {}),

@@ -217,6 +217,11 @@ typedef struct {
    * the epilogue and leaves the scratch zeroed for the next launch.  NULL: never split. */
   void* acc_ws;
   int64_t acc_ws_bytes;
+  /* optional residual given at HALF resolution, f32 [B][H/2][W/2][Cout]: upsample_2d ([1,3,3,1] FIR,
+   * up_or_down_sampling.py:181-216) of it is added before `scale`, evaluated in the epilogue with the tap
+   * order of fdbm_resample2x - the progressive-output pyramid (ncsnpp_v2.py:379-383) without its own
+   * upsampling launch.  H and W even. */
+  const float* res_up2x;
 } fdbm_conv_args;
 
 int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream);

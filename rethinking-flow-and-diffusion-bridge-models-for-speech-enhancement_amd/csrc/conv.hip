@@ -611,7 +611,8 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   }
   p.nseg = a->nseg;
   p.w = a->w; p.bias = a->bias; p.tbias = a->tbias; p.tbias_stride = a->tbias_stride;
-  p.res = a->res; p.scale = a->scale; p.out = a->out;
+  p.res = a->res; p.res_lo = a->res_up2x; p.scale = a->scale; p.out = a->out;
+  FDBM_CHECK(!a->res_up2x || (a->H % 2 == 0 && a->W % 2 == 0), "fdbm_conv_igemm: res_up2x needs even H, W (got %d x %d)", a->H, a->W);
   p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.CoutPad = a->CoutPad;
   p.nk = nk;
   int bm, bn, ks, kind, th;

@@ -43,6 +43,7 @@ struct ConvParams {
   const float* tbias;
   int tbias_stride;
   const void* res;
+  const float* res_lo;   // residual at half resolution, f32 [B][H/2][W/2][Cout]: upsampled 2x in the epilogue
   float scale;
   void* out;
   int B, H, W, Cout, CoutPad;
@@ -105,6 +106,32 @@ __device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int64_t m, i
     float r[4];
     OutVec<TO>::load(reinterpret_cast<const TO*>(p.res) + m * Cout + n, r);
     v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
+  }
+  if (p.res_lo) {       // upsample_2d of the low-resolution residual, tap order of resample2x_kernel
+    const int HW = p.H * p.W;
+    const int rr = (int)(m - b * HW);
+    const int y = rr / p.W, x = rr - y * p.W;
+    const int H2 = p.H >> 1, W2 = p.W >> 1;
+    const int iy = y >> 1, ix = x >> 1;
+    int ys[2], xs[2];
+    float wy[2], wx[2];
+    if (y & 1) { ys[0] = iy; wy[0] = 0.75f; ys[1] = iy + 1; wy[1] = 0.25f; }
+    else       { ys[0] = iy - 1; wy[0] = 0.25f; ys[1] = iy; wy[1] = 0.75f; }
+    if (x & 1) { xs[0] = ix; wx[0] = 0.75f; xs[1] = ix + 1; wx[1] = 0.25f; }
+    else       { xs[0] = ix - 1; wx[0] = 0.25f; xs[1] = ix; wx[1] = 0.75f; }
+    float up[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      if (ys[a] < 0 || ys[a] >= H2) continue;
+#pragma unroll
+      for (int bx = 0; bx < 2; ++bx) {
+        if (xs[bx] < 0 || xs[bx] >= W2) continue;
+        const float wgt = wy[a] * wx[bx];
+        const f32x4 q = *reinterpret_cast<const f32x4*>(p.res_lo + (((int64_t)b * H2 + ys[a]) * W2 + xs[bx]) * Cout + n);
+        up[0] += wgt * q[0]; up[1] += wgt * q[1]; up[2] += wgt * q[2]; up[3] += wgt * q[3];
+      }
+    }
+    v[0] += up[0]; v[1] += up[1]; v[2] += up[2]; v[3] += up[3];
   }
   v[0] *= p.scale; v[1] *= p.scale; v[2] *= p.scale; v[3] *= p.scale;
   if (p.comb_pyr) {

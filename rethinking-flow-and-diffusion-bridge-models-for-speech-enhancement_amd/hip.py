@@ -42,7 +42,7 @@ class ConvArgs(ctypes.Structure):
                 ("stat_out", c_void_p), ("stat_G", ctypes.c_int32), ("stat_nsplit", ctypes.c_int32),
                 ("w_frag", c_void_p),
                 ("gn_seg_sums", c_void_p * MAX_SEG), ("gn_seg_nsplit", ctypes.c_int32 * MAX_SEG),
-                ("acc_ws", c_void_p), ("acc_ws_bytes", c_i64)]
+                ("acc_ws", c_void_p), ("acc_ws_bytes", c_i64), ("res_up2x", c_void_p)]
 
 
 class Op(ctypes.Structure):

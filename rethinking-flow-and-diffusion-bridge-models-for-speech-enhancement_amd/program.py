@@ -308,7 +308,7 @@ class Program:
         return sum(taps * ((cin + kc - 1) // kc) for (_, _, cin, taps) in segs)
 
     def conv(self, segs, wpack, cout_pad, cout, bias, out_dtype=None, tbias=None, tb_stride=0,
-             res=None, scale=1.0, gn=None, comb=None, want_stats=0):
+             res=None, scale=1.0, gn=None, comb=None, want_stats=0, res_up=None):
         """segs: list of (Act, coff, cin, taps).
         gn: (stats, gamma, beta, G, C, silu, n_flagged_segments) -> fused GroupNorm prologue.
         comb: (pyr Act, w, b) -> fused Combine.  want_stats: G of the consuming GroupNorm (0: none)."""
@@ -336,6 +336,9 @@ class Program:
         ca.tbias = tbias if tbias else 0
         ca.tbias_stride = tb_stride
         ca.res = res.ptr if res is not None else 0
+        if res_up is not None:               # f32 [B][H/2][W/2][cout]: upsampled 2x inside the epilogue
+            assert res_up.dtype == torch.float32 and res_up.H * 2 == a0.H and res_up.W * 2 == a0.W and res_up.C == cout
+            ca.res_up2x = res_up.ptr
         ca.scale = scale
         ca.out = out.ptr
         ca.B, ca.H, ca.W, ca.Cout, ca.CoutPad = self.B, a0.H, a0.W, cout, cout_pad
@@ -593,14 +596,7 @@ class Program:
 
         pyramid = None
         for lvl in reversed(range(nres)):
-            # the previous level's output pyramid is upsampled on the side lane beside this level's res-blocks
-            up_pyr, ev_up = None, None
-            if pyramid is not None:
-                self.fork()
-                self.lane = 1
-                up_pyr, _ = self.resample(pyramid, True)
-                ev_up = self.mark()
-                self.lane = 0
+            # (the previous level's output pyramid is upsampled inside this level's head conv: res_up)
             for _ in range(spec.num_res_blocks + 1):
                 skip = hs.pop()
                 hn = self.resblock(nxt(), [h, skip])
@@ -614,9 +610,7 @@ class Program:
             gnm, head = nxt(), nxt()
             G = gn_groups(h.C)
             gw, hw = net.w[gnm.idx], net.w[head.idx]
-            if ev_up is not None:
-                self.join(ev_up)
-                self.free_act(pyramid)
+            prev_pyr = pyramid
             segs = [(h, 0, h.C, 9)]
             a = None
             fuse = self.fused and self.prologue_pays(h, IN_CH, segs) and self.tile_ok(h, IN_CH, segs)
@@ -628,12 +622,12 @@ class Program:
                 a = self.gn_apply([h], st, gw["w"], gw["b"], G, True)
                 segs = [(a, 0, h.C, 9)]
             pyramid = self.conv(segs, hw["w"], hw["pad"], IN_CH, hw["b"],
-                                out_dtype=torch.float32, res=up_pyr, scale=1.0, gn=gn)
+                                out_dtype=torch.float32, res_up=prev_pyr, scale=1.0, gn=gn)
+            if prev_pyr is not None:
+                self.free_act(prev_pyr)
             self.release_stats(st, own)
             if a is not None:
                 self.free_act(a)
-            if up_pyr is not None:
-                self.free_act(up_pyr)
             if lvl != 0:
                 hn = self.resblock(nxt(), [h])
                 self.free_act(h)

@@ -192,7 +192,7 @@ def test_resample2x(dtype, tol, up, shape):
 
 
 def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=None, scale=1.0, splitk=False,
-             gn=None, comb=None, stat_G=0):
+             gn=None, comb=None, stat_G=0, res_up=None):
     """segs_nchw: list of (x NCHW cpu tensor, taps); weights: list of W [Cout, cin, k, k] per seg."""
     out_dtype = out_dtype or dtype
     kc = hip.conv_kc(hip.dt_code(dtype))
@@ -217,6 +217,8 @@ def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=No
     ca.tbias_stride = tb.shape[1] if tb is not None else 0
     rd = nhwc(res, out_dtype) if res is not None else None
     ca.res = hip.ptr(rd)
+    rud = nhwc(res_up) if res_up is not None else None          # f32 NHWC at half resolution
+    ca.res_up2x = hip.ptr(rud)
     ca.scale = scale
     out = torch.full((B, H, W, cout), float("nan"), device=DEV, dtype=out_dtype)
     ca.out = out.data_ptr()
@@ -300,6 +302,9 @@ CONV_CASES = [
     ("tap_32_b2", 2, 32, 32, [128], 64, 9, dict(res=True, tbias=True)),
     ("tap_8x8_c96", 3, 8, 8, [96, 32], 96, 9, dict(shortcut=[96])),
     ("tap_4x8", 2, 4, 8, [64], 32, 9, {}),
+    ("head_up_patch", 1, 128, 128, [128], 4, 9, dict(head_up=True)),            # residual upsampled in the epilogue
+    ("head_up_tap", 2, 16, 16, [64], 4, 9, dict(head_up=True)),
+    ("head_up_tapouter", 1, 12, 20, [64], 4, 9, dict(head_up=True)),
 ]
 
 
@@ -341,6 +346,11 @@ def test_conv_igemm(case, dtype, splitk, conv_kernels):
         r = rnd(B, cout, H, W, seed=70)
         ref = (ref + q(r)) / math.sqrt(2.0)
         kw.update(res=r, scale=1 / math.sqrt(2.0))
+    if extra.get("head_up"):
+        out_dtype = torch.float32
+        r = rnd(B, cout, H // 2, W // 2, seed=72)
+        ref = ref + onet.upsample_2d(r)
+        kw.update(res_up=r, scale=1.0)
     if extra.get("head"):
         out_dtype = torch.float32
         r = rnd(B, cout, H, W, seed=71)

@@ -166,10 +166,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # FDBM_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
+    # (ranks share devices, the gather goes through host memory); the real runs use RCCL
+    backend = os.environ.get("FDBM_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
@@ -181,9 +189,16 @@ def main():
 
     def step():
         x_hat, X = hp.enhance(wave)
+        if os.environ.get("FDBM_BENCH_DEBUG"):
+            torch.cuda.synchronize()
+            print(f"[dbg] rank {rank}: wave finite {bool(torch.isfinite(wave).all())} max {float(wave.abs().max()):.3g}; "
+                  f"X finite {bool(torch.isfinite(torch.view_as_real(X)).all())}; x_hat finite {bool(torch.isfinite(x_hat).all())}",
+                  file=sys.stderr, flush=True)
         if world > 1:
             import torch.distributed as dist
             xr = torch.view_as_real(X.contiguous())
+            if backend != "nccl":
+                xr = xr.cpu()
             gathered = [torch.empty_like(xr) for _ in range(world)] if rank == 0 else None
             dist.gather(xr, gathered, dst=0)                     # enhanced spectrograms only, over RCCL/xGMI
         return x_hat
@@ -203,10 +218,10 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    assert torch.isfinite(out).all()
+    assert torch.isfinite(out).all(), f"rank {rank}: {int((~torch.isfinite(out)).sum())} non-finite samples of {out.numel()}"
 
     audio_s = world * args.steps * args.batch * CLIP_SECONDS
     rtf = audio_s / elapsed

@@ -373,14 +373,19 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
       const int n = n0 + j * 16 + fk * 4;
       if (n < Cout) {
         float* dst = p.partial + m * Cout + n;
-        atomicAdd(dst, s[0]); atomicAdd(dst + 1, s[1]); atomicAdd(dst + 2, s[2]); atomicAdd(dst + 3, s[3]);
+        // RETURNING atomics: their completion (not just their issue) is what the wait below observes
+        const float o0 = atomicAdd(dst, s[0]), o1 = atomicAdd(dst + 1, s[1]);
+        const float o2 = atomicAdd(dst + 2, s[2]), o3 = atomicAdd(dst + 3, s[3]);
+        asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3));
       }
     }
     // No agent-scope fence here: a fence would write back this XCD's whole L2 (the previous kernels' output,
-    // tens of microseconds).  Everything exchanged through the scratch is an agent-scope atomic - performed
-    // at the device coherence point and acknowledged before vmcnt reaches 0 - so waiting for this workgroup's
-    // atomics (workgroup-scope release = s_waitcnt, then the barrier) orders them before the counter add.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    // tens of microseconds).  Everything exchanged through the scratch is an agent-scope atomic performed at
+    // the device coherence point.  But the adds of THIS workgroup must all have been performed before it
+    // counts itself in: an explicit s_waitcnt on every counter (a workgroup-scope fence / __syncthreads does
+    // not wait for vmcnt outside threadgroup-split mode - without this wait a late add can land after the
+    // last workgroup has read and re-zeroed the scratch, seen only when the GPU is shared between processes).
+    __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     int* counter = reinterpret_cast<int*>(p.partial + (int64_t)p.B * H * W * Cout) + blockIdx.x * gridDim.y + blockIdx.y;
     int* s_flag = reinterpret_cast<int*>(s_stat + 128);

@@ -16,10 +16,26 @@ void fdbm_set_error(const char* fmt, ...) {
 extern "C" const char* fdbm_last_error(void) { return g_err; }
 extern "C" int fdbm_version(void) { return 1; }
 
+// A kernel of our own, not hipMemsetAsync: inside a replayed HIP graph the runtime's memset node stopped
+// zeroing after an unrelated synchronous device-to-host copy in the same process (ROCm 7.2; the statistics
+// arena then accumulated across forwards) - a plain kernel node has no such dependence on runtime state.
+__global__ void __launch_bounds__(256) zero_kernel(uint4* __restrict__ p, int64_t n16, unsigned char* __restrict__ tail,
+                                                   int ntail) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
+    p[i] = uint4{0u, 0u, 0u, 0u};
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+
 extern "C" int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream) {
   FDBM_CHECK(ptr && bytes >= 0, "fdbm_memset_zero: bad arguments");
-  hipError_t e = hipMemsetAsync(ptr, 0, (size_t)bytes, (hipStream_t)stream);
-  FDBM_CHECK(e == hipSuccess, "fdbm_memset_zero: %s", hipGetErrorString(e));
+  FDBM_CHECK(((uintptr_t)ptr & 15) == 0, "fdbm_memset_zero: pointer must be 16-byte aligned");
+  if (bytes == 0) return 0;
+  const int64_t n16 = bytes / 16;
+  int g = (int)((n16 + 255) / 256);
+  if (g > 1024) g = 1024;
+  if (g < 1) g = 1;
+  zero_kernel<<<g, 256, 0, (hipStream_t)stream>>>((uint4*)ptr, n16, (unsigned char*)ptr + n16 * 16, (int)(bytes - n16 * 16));
+  FDBM_LAUNCH_CHECK("fdbm_memset_zero");
   return 0;
 }
 

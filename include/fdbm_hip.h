@@ -313,7 +313,8 @@ typedef struct {
  * the only objects the library ever creates) */
 int fdbm_runtime_init_side(void);
 
-int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream);
+int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream);   /* a kernel, not hipMemsetAsync (16-byte aligned ptr) */
+int fdbm_copy_f32(float* dst, const float* src, int64_t n, void* stream);   /* a kernel, not hipMemcpyAsync */
 int fdbm_run_program(const fdbm_op* ops_host, int n_ops, void* stream);
 
 /* ------------------------------------------------------------------ composed backbone

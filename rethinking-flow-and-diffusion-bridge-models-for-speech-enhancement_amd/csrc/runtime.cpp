@@ -39,6 +39,21 @@ extern "C" int fdbm_memset_zero(void* ptr, int64_t bytes, void* stream) {
   return 0;
 }
 
+__global__ void copy_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+// small device-to-device copy as a kernel of the library (inside replayed graphs: see fdbm_memset_zero)
+extern "C" int fdbm_copy_f32(float* dst, const float* src, int64_t n, void* stream) {
+  FDBM_CHECK(dst && src && n >= 0, "fdbm_copy_f32: bad arguments");
+  if (n == 0) return 0;
+  int g = (int)((n + 255) / 256);
+  if (g > 1024) g = 1024;
+  copy_f32_kernel<<<g, 256, 0, (hipStream_t)stream>>>(dst, src, n);
+  FDBM_LAUNCH_CHECK("fdbm_copy_f32");
+  return 0;
+}
+
 // ---- side lane -------------------------------------------------------------------------------------
 static hipStream_t g_side = nullptr;
 static hipEvent_t g_ev[FDBM_MAX_EVENTS];

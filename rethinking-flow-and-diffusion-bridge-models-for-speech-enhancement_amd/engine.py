@@ -38,7 +38,7 @@ class SamplerGraph:
         n = prog.x_in[0].numel()
         B = prog.B
         for i in range(self.N):
-            prog.t_in.copy_(self.t_tab[i])
+            hip.call("fdbm_copy_f32", hip.ptr(prog.t_in), hip.ptr(self.t_tab[i]), B)     # (a library kernel inside the graph)
             prog.run()
             third = prog.y_in if self.kind == "ode" else self.z[i]
             w = self.table[i]

@@ -62,6 +62,7 @@ _SIGS = {
     "fdbm_unpack_output": [c_void_p] * 4 + [c_int] * 4,
     "fdbm_temb": [c_void_p] * 8 + [c_int] * 2,
     "fdbm_dense_rows": [c_void_p] * 4 + [c_int] * 3,
+    "fdbm_copy_f32": [c_void_p, c_void_p, c_i64],
     "fdbm_conv_stem": [c_void_p] * 4 + [c_int] * 5,
     "fdbm_conv_stem_stats": [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_int],
     "fdbm_gn_stats": [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 5,

@@ -157,9 +157,9 @@ def test_graph_replay_survives_host_copies(golden):
         x = br.sampler(m, y, generator=torch.Generator().manual_seed(5), use_graph=True)
         outs.append(torch.view_as_real(x.contiguous()).cpu())          # the host copy
     assert all(torch.isfinite(o).all() for o in outs)
-    scale = outs[0].abs().max().item()
-    for o in outs[1:]:
-        assert (o - outs[0]).abs().max().item() < 5e-2 * scale        # bf16 mode: atomics order varies in the last bits
+    for o in outs[1:]:        # bf16 mode: the atomics' order varies in the last bits and the random-weight net amplifies it
+        rel = ((o - outs[0]).pow(2).sum() / outs[0].pow(2).sum()).sqrt().item()
+        assert rel < 3e-2, rel
 
 
 def _toy_model(xt, y, t):

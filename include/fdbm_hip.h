@@ -89,11 +89,11 @@ int fdbm_dense_rows(float* out, const float* act, const float* w, const float* b
 int fdbm_conv_stem(void* out, const float* in, const float* w, const float* bias, int B, int H,
                    int W, int nf, int dt_out, void* stream);
 /* the same, also accumulating the UNIT statistics of the stored output ((sum, sumsq) per image and
- * 4 channels, [B][stat_nsplit][nf/4][2], atomics into a zeroed buffer - the layout of
+ * 4 channels, double [B][stat_nsplit][nf/4][2], atomics into a zeroed buffer - the layout of
  * fdbm_conv_args.stat_out with stat_G = nf/4) for the GroupNorms that read the stem's output;
  * needs nf/8 to divide 256.  stat_out NULL = fdbm_conv_stem. */
 int fdbm_conv_stem_stats(void* out, const float* in, const float* w, const float* bias, int B, int H,
-                         int W, int nf, int dt_out, float* stat_out, int stat_nsplit, void* stream);
+                         int W, int nf, int dt_out, double* stat_out, int stat_nsplit, void* stream);
 
 /* ------------------------------------------------------------------ GroupNorm
  * nn.GroupNorm(min(C/4,32), C, eps=1e-6) (layerspp.py:67,219,231; ncsnpp_v2.py:205,217)
@@ -132,9 +132,9 @@ int fdbm_upfirdn2d(float* out, const float* in, const float* kernel, int major, 
 int fdbm_resample2x(void* out_plain, void* out_act, const void* in, const float* stats, int nsplit,
                     int64_t count, float eps, const float* gamma, const float* beta, int B, int H,
                     int W, int C, int G, int up, int dtype, void* stream);
-/* the same with UNIT statistics: stats rows hold G * stat_units (sum, sumsq) entries, stat_units
- * consecutive ones per group - what a convolution's stat_out leaves with stat_G = C/4
- * (stat_units = C/G/4); stat_units = 1 is fdbm_resample2x. */
+/* the same with UNIT statistics: `stats` points to DOUBLES, nsplit = -(number of partial rows), rows
+ * hold G * stat_units (sum, sumsq) entries, stat_units consecutive ones per group - what a
+ * convolution's stat_out leaves with stat_G = C/4 (stat_units = C/G/4). */
 int fdbm_resample2x_units(void* out_plain, void* out_act, const void* in, const float* stats,
                           int nsplit, int stat_units, int64_t count, float eps, const float* gamma,
                           const float* beta, int B, int H, int W, int C, int G, int up, int dtype,
@@ -193,7 +193,7 @@ typedef struct {
    * adds into row blockIdx.x % stat_nsplit so the atomics do not all hit one address) - the
    * statistics the consuming GroupNorm needs, without another pass over the tensor; same layout
    * as fdbm_gn_stats' partial sums. */
-  float* stat_out;
+  double* stat_out;     /* fp64: the order of the atomics then does not show in the statistics */
   int32_t stat_G;
   int32_t stat_nsplit;
   /* optional: the same packed weights in MFMA-fragment-major order
@@ -202,19 +202,20 @@ typedef struct {
    * from it with 1 KiB-contiguous wave loads.  NULL: kind 2 is never selected. */
   const void* w_frag;
   /* optional, instead of gn_sums: UNIT statistics of the GroupNorm input, one buffer per flagged
-   * segment s: gn_seg_sums[s] = float [B][gn_seg_nsplit[s]][cin_s/4][2], (sum, sumsq) over units of
+   * segment s: gn_seg_sums[s] = double [B][gn_seg_nsplit[s]][cin_s/4][2], (sum, sumsq) over units of
    * 4 channels - exactly what a convolution writing that tensor leaves in stat_out with
    * stat_G = Cout/4.  Any GroupNorm whose group size is a multiple of 4 (all of NCSN++'s) is then
    * normalised from its producers' epilogues, also across a channel concatenation whose group
    * boundaries straddle the sources (e.g. 256 + 128 channels, 32 groups of 12).  The flagged
    * segments must be segments 0 .. n-1 (seg_gn_mask = 2^n - 1). */
-  const float* gn_seg_sums[FDBM_MAX_SEG];
+  const double* gn_seg_sums[FDBM_MAX_SEG];
   int32_t gn_seg_nsplit[FDBM_MAX_SEG];
-  /* optional: ZERO-INITIALISED scratch of at least M*Cout*4 + 4096 bytes.  When given, the
-   * wave-per-tap kernel may split the input-channel chunks of a small-map convolution over several
-   * workgroups that add their partial tiles into it (fp32 atomics; the summation order, and so the
-   * last bit of the result, then varies from run to run); the workgroup that finishes last applies
-   * the epilogue and leaves the scratch zeroed for the next launch.  NULL: never split. */
+  /* optional: ZERO-INITIALISED scratch of at least 65536 + 2*M*Cout*4 bytes (65536 + 8*M*Cout*4 lets it use
+   * up to 8 slices).  When given, the wave-per-tap kernel may split the input-channel chunks of a small-map
+   * convolution over several workgroups; each writes its partial tile into its own fp32 slab and the one
+   * that finishes last sums the slabs in slice order (results are run-to-run identical) and applies the
+   * epilogue.  Only the arrival counters (the first 64 KiB) need the zero initialisation; they are left
+   * zeroed for the next launch.  NULL: never split. */
   void* acc_ws;
   int64_t acc_ws_bytes;
   /* optional residual given at HALF resolution, f32 [B][H/2][W/2][Cout]: upsample_2d ([1,3,3,1] FIR,

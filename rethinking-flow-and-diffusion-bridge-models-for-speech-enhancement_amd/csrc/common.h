@@ -60,8 +60,8 @@ template <typename T> __device__ __forceinline__ float silu_t(float x) {
 // GroupNorm statistics -> per-channel scale/shift in LDS (s_ss[0..C) scale, s_ss[C..2C) shift).
 // stats: nsplit == 0: final [B][G][2] (mean, rstd);  nsplit > 0: float partial (sum, sumsq)
 // [B][nsplit][G][2];  nsplit < 0: the same with |nsplit| splits stored as doubles.  Reduced
-// here in fp64 in a fixed order.  G <= 32, blockDim.x == 256.  upg > 1 (float partials only): the
-// rows hold G * upg entries, upg consecutive ones per group (unit statistics, see fdbm_conv_args).
+// here in fp64 in a fixed order.  G <= 32, blockDim.x == 256.  upg >= 1 (fp64 partials): the rows
+// hold G * upg entries, upg consecutive ones per group (unit statistics, see fdbm_conv_args).
 __device__ __forceinline__ void gn_scale_shift(float* s_ss, double* s_red /*[8][32][2]*/,
                                                const float* __restrict__ stats, int nsplit,
                                                double inv_count, float eps, int b, int C, int G,
@@ -78,17 +78,17 @@ __device__ __forceinline__ void gn_scale_shift(float* s_ss, double* s_red /*[8][
       if (nsplit < 0) {          // fp64 partials (f32 parity mode)
         const double* sd = reinterpret_cast<const double*>(stats);
         for (int sp = part; sp < -nsplit; sp += 8) {
-          const double* q = sd + (((int64_t)b * (-nsplit) + sp) * G + g) * 2;
-          a0 += q[0];
-          a1 += q[1];
+          const double* q = sd + (((int64_t)b * (-nsplit) + sp) * G + g) * upg * 2;
+          for (int k = 0; k < upg; ++k) {
+            a0 += q[2 * k];
+            a1 += q[2 * k + 1];
+          }
         }
       } else {
         for (int sp = part; sp < nsplit; sp += 8) {
-          const float* q = stats + (((int64_t)b * nsplit + sp) * G + g) * upg * 2;
-          for (int k = 0; k < upg; ++k) {
-            a0 += (double)q[2 * k];
-            a1 += (double)q[2 * k + 1];
-          }
+          const float* q = stats + (((int64_t)b * nsplit + sp) * G + g) * 2;
+          a0 += (double)q[0];
+          a1 += (double)q[1];
         }
       }
     }

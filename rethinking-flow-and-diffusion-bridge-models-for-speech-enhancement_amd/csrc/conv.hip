@@ -81,13 +81,14 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
 
   // ---- GroupNorm prologue table + output-statistics scratch (after the two LDS buffers) ----
   float* s_gn = reinterpret_cast<float*>(smem + KG * 2 * BUF);               // scale[nb][gn_C] | shift[nb][gn_C] (second half)
-  float* s_stat = reinterpret_cast<float*>(smem + KG * 2 * BUF + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0));  // [nb][32][2]
+  double* s_stat = reinterpret_cast<double*>(smem + KG * 2 * BUF + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0));  // [nb][32][2] doubles
+  float* s_mr = reinterpret_cast<float*>(s_stat + CONV_MAX_NB * 64);                                        // [nb][32][2] mean, rstd
   const int b0 = (int)(m0 / HW);
   int pbl[AROWS];
 #pragma unroll
   for (int i = 0; i < AROWS; ++i) pbl[i] = (int)(pbase[i] / HW) - b0;
   if (p.stat_out) {
-    for (int i = threadIdx.x; i < CONV_MAX_NB * 64; i += NTHR) s_stat[i] = 0.f;
+    for (int i = threadIdx.x; i < CONV_MAX_NB * 64; i += NTHR) s_stat[i] = 0.0;
   }
   __syncthreads();
 
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
       const int64_t mlast = min(M, m0 + BM) - 1;
       const int nb = (int)(mlast / HW) - b0 + 1;
       // (scratch: the LDS tile buffers, not written before the barrier that follows)
-      conv_gn_table<NTHR>(p, b0, nb, s_gn, CONV_MAX_NB * CONV_GN_MAXC, s_stat + CONV_MAX_NB * 64, smem);
+      conv_gn_table<NTHR>(p, b0, nb, s_gn, CONV_MAX_NB * CONV_GN_MAXC, s_mr, smem);
     }
   };
 
@@ -359,8 +360,8 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
           const float r1 = row16_sum(s1), r2 = row16_sum(s2);
           if (owner && frow == 0 && mt0 < M && n < Cout) {
             const int bl = (int)(mt0 / HW) - b0;
-            atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2], r1);
-            atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2 + 1], r2);
+            atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2], (double)r1);
+            atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2 + 1], (double)r2);
           }
         }
       }
@@ -374,8 +375,8 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
       const float r1 = row16_sum(a1[j]), r2 = row16_sum(a2[j]);
       if (owner && frow == 0 && mw < M && n < Cout) {
         const int bl = (int)(mw / HW) - b0;
-        atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2], r1);
-        atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2 + 1], r2);
+        atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2], (double)r1);
+        atomicAdd(&s_stat[(bl * 32 + (n - n0) / scpg) * 2 + 1], (double)r2);
       }
     }
   }
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
 // output statistics of a block belong to one (image, group) row.
 template <typename TO>
 __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParams p) {
-  __shared__ float s_stat[128];          // up to 64 groups (Cout / 4 with Cout <= 256)
+  __shared__ double s_stat[128];         // up to 64 groups (Cout / 4 with Cout <= 256)
   const int Cout = p.Cout;
   const int HW = p.H * p.W;
   const int64_t M = (int64_t)p.B * HW;
@@ -408,7 +409,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParam
   const bool do_stat = p.stat_out != nullptr;
   const int scpg = do_stat ? Cout / p.stat_G : 1;
   if (do_stat) {
-    if (threadIdx.x < 128) s_stat[threadIdx.x] = 0.f;
+    if (threadIdx.x < 128) s_stat[threadIdx.x] = 0.0;
     __syncthreads();
   }
   const int total = HW * nv;
@@ -432,8 +433,8 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParam
     conv_epilogue4<TO>(p, m, b, n, v);
     if (do_stat) {
       const int g = n / scpg;
-      atomicAdd(&s_stat[g * 2], (v[0] + v[1]) + (v[2] + v[3]));
-      atomicAdd(&s_stat[g * 2 + 1], (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]));
+      atomicAdd(&s_stat[g * 2], (double)((v[0] + v[1]) + (v[2] + v[3])));
+      atomicAdd(&s_stat[g * 2 + 1], (double)((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])));
     }
   }
   if (do_stat) {
@@ -446,7 +447,7 @@ __global__ void __launch_bounds__(256) conv_splitk_reduce_kernel(const ConvParam
 
 template <typename T, typename TO, int BM, int BN, bool GNP, int KG>
 static int launch_conv(const ConvParams& p, hipStream_t st) {
-  constexpr int SMEM = KG * 2 * (BM + BN) * 128 + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0) + CONV_MAX_NB * 64 * 4 * 2;
+  constexpr int SMEM = KG * 2 * (BM + BN) * 128 + (GNP ? CONV_MAX_NB * CONV_GN_MAXC * 8 : 0) + CONV_MAX_NB * 64 * 8 + CONV_MAX_NB * 64 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<T, TO, BM, BN, GNP, KG>),
@@ -662,7 +663,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
         uoff += a->seg[s].cin / 4;
       }
       p.gn_unit = 1;
-      p.gn_sums = a->gn_seg_sums[0];            // non-null = "prologue on" for the launchers
+      p.gn_sums = reinterpret_cast<const float*>(a->gn_seg_sums[0]);   // non-null = "prologue on" for the launchers
     } else {
       p.gn_sums = a->gn_sums;
     }
@@ -699,12 +700,13 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     for (int s = 0; s < a->nseg; ++s) nchunks += (a->seg[s].cin + kc - 1) / kc;
     const int tw = th, tr = tw == 16 ? 4 : tw == 8 ? 8 : 4;
     const int64_t blocks = (int64_t)a->B * (a->H / tr) * (a->W / tw) * ((a->Cout + bn - 1) / bn);
-    const int64_t need = M * a->Cout * 4 + blocks * 4;
     static const char* smin = getenv("FDBM_TAP_SPLIT_MIN");     // experiments
-    if (a->acc_ws && a->acc_ws_bytes >= need && blocks <= 128 && nchunks >= (smin ? atoi(smin) : 8)) {
+    if (a->acc_ws && blocks <= 128 && nchunks >= (smin ? atoi(smin) : 8)) {
       int ks = (int)(256 / blocks);
       if (ks > nchunks / 2) ks = nchunks / 2;
       if (ks > 8) ks = 8;
+      if (blocks * 4 > 65536) ks = 1;
+      while (ks > 1 && (int64_t)ks * M * a->Cout * 4 + 65536 > a->acc_ws_bytes) --ks;   // 64 KiB of counters, then one fp32 slab per slice
       if (ks > 1) { p.ksplit = ks; p.partial = reinterpret_cast<float*>(a->acc_ws); }
     }
     return fdbm_launch_conv_tap(p, a->dt_in, a->dt_out, th, bn / 16, st);

@@ -59,11 +59,11 @@ struct ConvParams {
   double gn_inv_count;
   float gn_eps;
   int seg_gn[FDBM_MAX_SEG];
-  // unit statistics (gn_unit != 0): per flagged segment s a buffer [B][gn_unsp[s]][gn_ucnt[s]][2] of
+  // unit statistics (gn_unit != 0): per flagged segment s a buffer of DOUBLES [B][gn_unsp[s]][gn_ucnt[s]][2] of
   // (sum, sumsq) over units of 4 channels, as the convs' stat_out leaves them with stat_G = Cout/4;
   // gn_uoff[s] = first unit of the segment inside the normalised (virtually concatenated) input
   int gn_unit;
-  const float* gn_useg[FDBM_MAX_SEG];
+  const double* gn_useg[FDBM_MAX_SEG];
   int gn_unsp[FDBM_MAX_SEG], gn_uoff[FDBM_MAX_SEG], gn_ucnt[FDBM_MAX_SEG];
   // Combine('sum') folded into the epilogue: out += comb_b[n] + comb_w[n][0..3] . pyr[m][0..3]
   const float* comb_pyr;
@@ -71,7 +71,7 @@ struct ConvParams {
   const float* comb_b;
   // (sum, sumsq) of the stored output per (image, group of Cout/stat_G channels), accumulated
   // with atomics into stat_out[B][stat_G][2] for the GroupNorm that consumes this tensor
-  float* stat_out;
+  double* stat_out;  // fp64: the atomics' order then changes the sums by ~1e-16, not by fp32 last bits
   int stat_G;
   int stat_nsplit;   // stat_out is [B][stat_nsplit][stat_G][2]; a block adds into split blockIdx.x % nsplit
 };
@@ -179,14 +179,14 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
     const int upg = (C / G) >> 2;
     for (int u = g * upg; u < (g + 1) * upg; ++u) {
       const int sg = (p.seg_gn[1] >= 0 && u >= p.gn_uoff[1]) ? ((p.seg_gn[2] >= 0 && u >= p.gn_uoff[2]) ? ((p.seg_gn[3] >= 0 && u >= p.gn_uoff[3]) ? 3 : 2) : 1) : 0;
-      const float* base = sg == 0 ? p.gn_useg[0] : sg == 1 ? p.gn_useg[1] : sg == 2 ? p.gn_useg[2] : p.gn_useg[3];
+      const double* base = sg == 0 ? p.gn_useg[0] : sg == 1 ? p.gn_useg[1] : sg == 2 ? p.gn_useg[2] : p.gn_useg[3];
       const int usp = sg == 0 ? p.gn_unsp[0] : sg == 1 ? p.gn_unsp[1] : sg == 2 ? p.gn_unsp[2] : p.gn_unsp[3];
       const int ucnt = sg == 0 ? p.gn_ucnt[0] : sg == 1 ? p.gn_ucnt[1] : sg == 2 ? p.gn_ucnt[2] : p.gn_ucnt[3];
       const int uoff = sg == 0 ? p.gn_uoff[0] : sg == 1 ? p.gn_uoff[1] : sg == 2 ? p.gn_uoff[2] : p.gn_uoff[3];
-      const float* sf = base + (((int64_t)(b0 + bl)) * usp * ucnt + (u - uoff)) * 2;
+      const double* sf = base + (((int64_t)(b0 + bl)) * usp * ucnt + (u - uoff)) * 2;
       for (int sp = part; sp < usp; sp += nparts) {
-        const float* q = sf + (int64_t)sp * ucnt * 2;
-        a0 += (double)q[0]; a1 += (double)q[1];
+        const double* q = sf + (int64_t)sp * ucnt * 2;
+        a0 += q[0]; a1 += q[1];
       }
     }
   } else if (g < G && part < nparts) {

@@ -39,7 +39,8 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   unsigned char* s_patch = smem;                          // 2 x PBUF
   unsigned char* s_w = smem + 2 * PBUF;                   // 2 x WBUF
   float* s_gn = reinterpret_cast<float*>(smem + 2 * PBUF + 2 * WBUF);                         // scale[gnpad] | shift[gnpad]
-  float* s_stat = reinterpret_cast<float*>(smem + 2 * PBUF + 2 * WBUF + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0));  // [32][2] + [32][2] (after the table)
+  double* s_stat = reinterpret_cast<double*>(smem + 2 * PBUF + 2 * WBUF + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0));  // [32][2] doubles (after the table)
+  float* s_mr = reinterpret_cast<float*>(s_stat + 64);                                    // [32][2] mean, rstd
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -72,12 +73,12 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   const int pchunk = tid & 7;          // NTHR is a multiple of 8: the 16-byte chunk is fixed per thread
 
   if (p.stat_out)
-    for (int i = tid; i < 64; i += NTHR) s_stat[i] = 0.f;
+    for (int i = tid; i < 64; i += NTHR) s_stat[i] = 0.0;
 
   auto build_gn_table = [&]() __attribute__((always_inline)) {
     // (scratch: the second patch buffer, idle until the first chunk's taps; the first weight tile is
     // being written to s_w meanwhile)
-    if constexpr (GNP) conv_gn_table<NTHR>(p, b, 1, s_gn, (p.gn_C + 63) & ~63, s_stat + 64, s_patch + PBUF);
+    if constexpr (GNP) conv_gn_table<NTHR>(p, b, 1, s_gn, (p.gn_C + 63) & ~63, s_mr, s_patch + PBUF);
   };
 
   // ---- chunk cursor -------------------------------------------------------------------------------
@@ -303,8 +304,8 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
       const int n = n0 + wn * 64 + j * 16 + fk * 4;
       const float r1 = row16_sum(a1[j]), r2 = row16_sum(a2[j]);
       if (frow == 0 && n < Cout) {
-        atomicAdd(&s_stat[((n - n0) / scpg) * 2], r1);
-        atomicAdd(&s_stat[((n - n0) / scpg) * 2 + 1], r2);
+        atomicAdd(&s_stat[((n - n0) / scpg) * 2], (double)r1);
+        atomicAdd(&s_stat[((n - n0) / scpg) * 2 + 1], (double)r2);
       }
     }
     __syncthreads();
@@ -321,10 +322,10 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
 template <typename T, typename TO, int TH, int BN, bool GNP>
 static int launch_patch(const ConvParams& p, hipStream_t st) {
   constexpr int NTHR = 64 * (TH / 4) * (BN / 64);
-  constexpr int SMEM_MAX = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 4 * 2;
+  constexpr int SMEM_MAX = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 8 + 64 * 4;
   // the GroupNorm table takes what the layer needs: with 8-row tiles and <= 256 normalised channels two
   // workgroups fit the 160 KiB of a CU
-  const int SMEM = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0) + 64 * 4 * 2;
+  const int SMEM = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0) + 64 * 8 + 64 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<T, TO, TH, BN, GNP>),

@@ -25,6 +25,7 @@
 #include "conv_common.h"
 
 #define TAP_NTHR 512
+#define TAP_SLAB0 16384      // floats: the split-accumulation slabs start 64 KiB into the scratch (counters first)
 
 // Diagnostic build only (-DFDBM_STAMPS, tools/tap_timeline.py): workgroup (0,0) writes shader-clock
 // stamps of its phases into the (otherwise unused) workspace.  The product library has none of it.
@@ -62,7 +63,8 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_patch = smem;                                         // 2 x PBUF (slabs alias it later)
   float* s_gn = reinterpret_cast<float*>(smem + MAIN);                   // scale[CONV_GN_MAXC] | shift[CONV_GN_MAXC]
-  float* s_stat = reinterpret_cast<float*>(smem + MAIN + (GNP ? CONV_GN_MAXC * 8 : 0));   // [32][2] + [32][2]
+  double* s_stat = reinterpret_cast<double*>(smem + MAIN + (GNP ? CONV_GN_MAXC * 8 : 0));  // [32][2] doubles
+  float* s_mr = reinterpret_cast<float*>(s_stat + 64);                                    // [32][2] mean, rstd
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -101,10 +103,10 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   constexpr int MROW = RPM * PCW;
 
   if (p.stat_out)
-    for (int i = tid; i < 64; i += TAP_NTHR) s_stat[i] = 0.f;
+    for (int i = tid; i < 64; i += TAP_NTHR) s_stat[i] = 0.0;
 
   auto build_gn_table = [&]() __attribute__((always_inline)) {
-    if constexpr (GNP) conv_gn_table<TAP_NTHR>(p, b, 1, s_gn, CONV_GN_MAXC, s_stat + 64, smem);   // (the patch buffers are still idle)
+    if constexpr (GNP) conv_gn_table<TAP_NTHR>(p, b, 1, s_gn, CONV_GN_MAXC, s_mr, smem);   // (the patch buffers are still idle)
   };
 
   auto seg_nch = [&](int s) __attribute__((always_inline)) { return (SEG_FIELD(p, s, cin) + KC - 1) / KC; };
@@ -225,9 +227,9 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
     }
   };
   // split over workgroups (p.ksplit > 1, grid.z): this workgroup owns chunks [zb, ze) of the conv and
-  // adds its partial tile into the zeroed fp32 scratch p.partial; the workgroup whose add comes last
-  // applies the epilogue (and leaves the scratch zeroed).  For maps so small that the tiles alone
-  // occupy a fraction of the chip and the chain over the chunks is the whole run time.
+  // writes its partial tile into slab blockIdx.z of the scratch p.partial; the workgroup that finishes
+  // last sums the slabs in slice order and applies the epilogue.  For maps so small that the tiles
+  // alone occupy a fraction of the chip and the chain over the chunks is the whole run time.
   int ntotal = 0;
   for (int s_ = 0; s_ < p.nseg; ++s_) ntotal += seg_nch(s_);
   const int zper = (ntotal + p.ksplit - 1) / p.ksplit;
@@ -363,8 +365,13 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   STAMP(28);
   const int Cout = p.Cout;
   const bool split = p.ksplit > 1;
+  const int64_t slab = (int64_t)p.B * H * W * Cout;          // floats per workgroup-slice slab
   if (split) {
-    // partial tile -> scratch (fp32 atomics at the device coherence point), then count this workgroup in
+    // partial tile -> this slice's slab in the scratch, then count this workgroup in.  Writes and reads of the
+    // slabs are atomic read-modify-writes (exchange / add 0): those are performed AT the device coherence
+    // point, whereas plain (even sc1) loads hit stale lines of an earlier launch in this XCD's L2 unless an
+    // agent-scope acquire invalidates it (measured: garbage) - and a release would write the whole L2 back.
+    float* mine = p.partial + TAP_SLAB0 + (int64_t)blockIdx.z * slab;
     for (int t = wave; t < MT * NT; t += 8) {
       const int j = t / MT, i = t - j * MT;
       const f32x4 s = (red[t * 64 + lane] + red[SL4 + t * 64 + lane]) + (red[2 * SL4 + t * 64 + lane] + red[3 * SL4 + t * 64 + lane]);
@@ -372,23 +379,24 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
       const int64_t m = img + (int64_t)y * W + x;
       const int n = n0 + j * 16 + fk * 4;
       if (n < Cout) {
-        float* dst = p.partial + m * Cout + n;
-        // RETURNING atomics: their completion (not just their issue) is what the wait below observes
-        const float o0 = atomicAdd(dst, s[0]), o1 = atomicAdd(dst + 1, s[1]);
-        const float o2 = atomicAdd(dst + 2, s[2]), o3 = atomicAdd(dst + 3, s[3]);
-        asm volatile("" ::"v"(o0), "v"(o1), "v"(o2), "v"(o3));
+        float* dst = mine + m * Cout + n;
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = __hip_atomic_exchange(dst + r, s[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]));     // returning: completion is what the wait below sees
       }
     }
     // No agent-scope fence here: a fence would write back this XCD's whole L2 (the previous kernels' output,
-    // tens of microseconds).  Everything exchanged through the scratch is an agent-scope atomic performed at
-    // the device coherence point.  But the adds of THIS workgroup must all have been performed before it
+    // tens of microseconds).  But the exchanges of THIS workgroup must all have completed before it
     // counts itself in: an explicit s_waitcnt on every counter (a workgroup-scope fence / __syncthreads does
-    // not wait for vmcnt outside threadgroup-split mode - without this wait a late add can land after the
-    // last workgroup has read and re-zeroed the scratch, seen only when the GPU is shared between processes).
+    // not wait for vmcnt outside threadgroup-split mode - without this wait the last workgroup can read a slab
+    // before its owner's stores have landed, seen only when the GPU is shared between processes).
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    int* counter = reinterpret_cast<int*>(p.partial + (int64_t)p.B * H * W * Cout) + blockIdx.x * gridDim.y + blockIdx.y;
-    int* s_flag = reinterpret_cast<int*>(s_stat + 128);
+    // (arrival counters live in the first 64 KiB of the scratch, which no launch ever uses for slabs: they
+    // are zero whenever no launch is in flight)
+    int* counter = reinterpret_cast<int*>(p.partial) + blockIdx.x * gridDim.y + blockIdx.y;
+    int* s_flag = reinterpret_cast<int*>(s_mr + 64);
     if (tid == 0) {
       const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       *s_flag = (old == p.ksplit - 1);
@@ -406,13 +414,13 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
     const int y = y0 + i * RPM + frow / TW, x = x0 + frow % TW;
     const int64_t m = img + (int64_t)y * W + x;
     const int n = n0 + j * 16 + fk * 4;
-    if (split && n < Cout) {                // the complete sums, read at the coherence point; scratch back to zero
-      float* src = p.partial + m * Cout + n;
+    if (split && n < Cout) {                // all slices' partial tiles, summed in slice order (run-to-run identical)
+      const float* src = p.partial + TAP_SLAB0 + m * Cout + n;
+      s = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int z = 0; z < p.ksplit; ++z)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        s[r] = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(src + r, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
+        for (int r = 0; r < 4; ++r)
+          s[r] += __hip_atomic_fetch_add(const_cast<float*>(src) + (int64_t)z * slab + r, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     float v[4] = {s[0], s[1], s[2], s[3]};
     const bool live = n < Cout;
@@ -422,8 +430,8 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
       const float s2 = live ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.f;
       const float r1 = row16_sum(s1), r2 = row16_sum(s2);
       if (frow == 0 && live) {
-        atomicAdd(&s_stat[((n - n0) / scpg) * 2], r1);
-        atomicAdd(&s_stat[((n - n0) / scpg) * 2 + 1], r2);
+        atomicAdd(&s_stat[((n - n0) / scpg) * 2], (double)r1);
+        atomicAdd(&s_stat[((n - n0) / scpg) * 2 + 1], (double)r2);
       }
     }
   }
@@ -447,7 +455,7 @@ static int launch_tap(const ConvParams& p, hipStream_t st) {
   constexpr int PBUF = (TR + 2) * (TW + 2) * 128;
   constexpr int SLAB = MT * NT * 1024;
   constexpr int MAIN = (2 * PBUF > 4 * SLAB) ? 2 * PBUF : 4 * SLAB;
-  constexpr int SMEM = MAIN + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 4 * 2 + 16;
+  constexpr int SMEM = MAIN + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 8 + 64 * 4 + 16;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tap_kernel<T, TO, TW, MT, NT, GNP>),

@@ -360,7 +360,7 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
                                                         const f32x4* __restrict__ in,
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias, int H,
-                                                        int W, int nf, float* __restrict__ stat_out,
+                                                        int W, int nf, double* __restrict__ stat_out,
                                                         int stat_nsplit) {
   extern __shared__ __attribute__((aligned(16))) float s_w[];  // [36][nf] (k-major) + [nf] bias + [nf/4][2] statistics
   float* s_st = s_w + nf * 37;
@@ -434,7 +434,7 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nf / 2; i += blockDim.x)
-      atomicAdd(stat_out + ((b * stat_nsplit + blockIdx.x % stat_nsplit) * (nf / 4)) * 2 + i, s_st[i]);
+      atomicAdd(stat_out + ((b * stat_nsplit + blockIdx.x % stat_nsplit) * (nf / 4)) * 2 + i, (double)s_st[i]);
   }
 }
 
@@ -447,14 +447,14 @@ template <typename T, int NT>
 __global__ void __launch_bounds__(256) conv_stem_mfma_kernel(T* __restrict__ out, const float* __restrict__ in,
                                                              const float* __restrict__ w,
                                                              const float* __restrict__ bias, int H, int W,
-                                                             float* __restrict__ stat_out, int stat_nsplit,
+                                                             double* __restrict__ stat_out, int stat_nsplit,
                                                              int tiles_per_wave) {
   constexpr int nf = 16 * NT;
   __shared__ float s_w[nf * 36 + nf];
-  __shared__ float s_st[nf / 2];
+  __shared__ double s_st[nf / 2];
   for (int i = threadIdx.x; i < nf * 36; i += 256) s_w[i] = w[i];
   for (int i = threadIdx.x; i < nf; i += 256) s_w[nf * 36 + i] = bias[i];
-  if (threadIdx.x < nf / 2) s_st[threadIdx.x] = 0.f;
+  if (threadIdx.x < nf / 2) s_st[threadIdx.x] = 0.0;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int frow = lane & 15, fk = lane >> 4;
@@ -509,8 +509,8 @@ __global__ void __launch_bounds__(256) conv_stem_mfma_kernel(T* __restrict__ out
     for (int j = 0; j < NT; ++j) {
       const float r1 = row16_sum(u1[j]), r2 = row16_sum(u2[j]);     // over the 16 pixels of the tile row
       if (frow == 0) {
-        atomicAdd(&s_st[(j * 4 + fk) * 2], r1);
-        atomicAdd(&s_st[(j * 4 + fk) * 2 + 1], r2);
+        atomicAdd(&s_st[(j * 4 + fk) * 2], (double)r1);
+        atomicAdd(&s_st[(j * 4 + fk) * 2 + 1], (double)r2);
       }
     }
     __syncthreads();
@@ -525,7 +525,7 @@ extern "C" int fdbm_conv_stem(void* out, const float* in, const float* w, const 
 }
 
 extern "C" int fdbm_conv_stem_stats(void* out, const float* in, const float* w, const float* bias, int B,
-                                    int H, int W, int nf, int dt_out, float* stat_out, int stat_nsplit,
+                                    int H, int W, int nf, int dt_out, double* stat_out, int stat_nsplit,
                                     void* stream) {
   FDBM_CHECK(out && in && w && bias, "fdbm_conv_stem: null pointer");
   FDBM_CHECK(nf % 8 == 0 && nf > 0 && nf <= 256, "fdbm_conv_stem: nf=%d must be a multiple of 8, <= 256", nf);

@@ -240,7 +240,7 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
                                      const float* gamma, const float* beta, int B, int H, int W, int C,
                                      int G, int up, int dtype, void* stream) {
   FDBM_CHECK(in && (out_plain || out_act), "fdbm_resample2x: null pointer");
-  FDBM_CHECK(stat_units >= 1 && (stat_units == 1 || nsplit > 0), "fdbm_resample2x: unit statistics are float partial sums (nsplit > 0)");
+  FDBM_CHECK(stat_units >= 1 && (stat_units == 1 || nsplit < 0), "fdbm_resample2x: unit statistics are fp64 partial sums (nsplit < 0)");
   FDBM_CHECK((out_act != nullptr) == (stats != nullptr), "fdbm_resample2x: out_act needs GroupNorm statistics (and vice versa)");
   FDBM_CHECK(!out_act || (gamma && beta && G > 0 && G <= 32 && C % G == 0 && C <= 1024), "fdbm_resample2x: bad GroupNorm arguments");
   FDBM_CHECK(nsplit == 0 || count > 0, "fdbm_resample2x: bad nsplit/count");

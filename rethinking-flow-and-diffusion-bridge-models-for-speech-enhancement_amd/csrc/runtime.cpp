@@ -131,7 +131,7 @@ extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* main_stream
         rc = fdbm_attention(P(0), CP(1), I(2), I(3), I(4), I(5), stream);
         break;
       case FDBM_OP_STEM:
-        rc = fdbm_conv_stem_stats(P(0), CFP(1), CFP(2), CFP(3), I(4), I(5), I(6), I(7), I(8), FP(9), I(10), stream);
+        rc = fdbm_conv_stem_stats(P(0), CFP(1), CFP(2), CFP(3), I(4), I(5), I(6), I(7), I(8), (double*)P(9), I(10), stream);
         break;
       case FDBM_OP_PACK:
         rc = fdbm_pack_input(FP(0), CP(1), CP(2), I(3), I(4), I(5), I(6), stream);

@@ -180,10 +180,10 @@ class Program:
         self.lane = 0
         self.n_events = 0
         self.fused = net.fused
-        # (sum, sumsq) slots [slot][B][32][2] that conv epilogues accumulate into with atomics;
+        # (sum, sumsq) fp64 slots [slot][B][nsplit][C/4][2] that conv epilogues accumulate into with atomics;
         # zeroed by ONE memset at the head of every forward
-        self.arena = torch.zeros(256 * 1024 * B, dtype=torch.float32, device=net.device)   # 1 MiB per sample
-        self.arena_used = 0        # floats
+        self.arena = torch.zeros(256 * 1024 * B, dtype=torch.float64, device=net.device)   # 2 MiB per sample (fp64 sums)
+        self.arena_used = 0        # doubles
         self.n_slots = 0
         self.macs = 0
         dev = self.dev
@@ -277,7 +277,7 @@ class Program:
     def new_slot(self, nsplit, G):
         n = self.B * nsplit * G * 2
         assert self.arena_used + n <= self.arena.numel()
-        ptr = self.arena.data_ptr() + self.arena_used * 4
+        ptr = self.arena.data_ptr() + self.arena_used * 8
         self.arena_used += (n + 63) // 64 * 64
         self.n_slots += 1
         return ptr
@@ -323,13 +323,12 @@ class Program:
         ca.w = wpack.data_ptr()
         if self.plan(a0, cout, segs)["kind"] == 2:
             ca.w_frag = self.net.frag_weight(wpack).data_ptr()
-            if self.fused and a0.M * cout * 4 <= (4 << 20):
-                # throughput mode: small-map convs may split their channel chunks over workgroups and
-                # combine through this zeroed scratch (fp32 atomics: run-to-run last-bit variation, as
-                # with the GroupNorm statistics); the parity mode stays deterministic
-                need = a0.M * cout * 4 + 65536
+            if self.fused and a0.M * cout * 4 <= (1 << 20):
+                # throughput mode: small-map convs may split their channel chunks over up to 8 workgroups that
+                # combine through this scratch (one fp32 slab per slice, summed in slice order: deterministic)
+                need = 8 * a0.M * cout * 4 + 65536
                 if self.acc_ws is None or self.acc_ws.numel() < need:
-                    self.acc_ws = torch.zeros(max(need, (4 << 20) + 65536), dtype=torch.uint8, device=self.dev)
+                    self.acc_ws = torch.zeros(max(need, (8 << 20) + 65536), dtype=torch.uint8, device=self.dev)
                     self.keep.append(self.acc_ws)
                 ca.acc_ws, ca.acc_ws_bytes = self.acc_ws.data_ptr(), self.acc_ws.numel()
         ca.bias = bias.data_ptr() if bias is not None else 0
@@ -395,6 +394,7 @@ class Program:
             pptr, nsplit, count = 0, 0, 0
         elif st[0] == "unit":
             (pptr, nsplit, _), = st[1]
+            nsplit = -nsplit                 # fp64 partial rows
             count = st[2]
             units = a.C // G // 4
         else:
@@ -641,7 +641,7 @@ class Program:
         self.macs_per_sample = self.macs       # self.macs was accumulated per sample (H*W, not B*H*W)
 
     def _finalize(self):
-        self.ops[self.op_memset][1][1] = max(64, self.arena_used * 4)
+        self.ops[self.op_memset][1][1] = max(64, self.arena_used * 8)
         n = len(self.ops)
         arr = (hip.Op * n)()
         for i, (opc, ia, fa, lane) in enumerate(self.ops):

@@ -159,6 +159,12 @@ class Spec:
         out.update(self.output_layer.params)
         return out
 
+    def param_order(self):
+        """Keys in the order of the reference module's `parameters()` (= its state_dict order; it has no buffers):
+        `output_layer` is registered before `all_modules` (ncsnpp_v2.py:93,239).  This is the order of torch_ema's
+        `shadow_params` in a Lightning checkpoint; pinned by tests/golden/param_order.json."""
+        return list(self.output_layer.params) + [k for m in self.mods for k in m.params]
+
     def num_params(self):
         n = 0
         for shp in self.param_shapes().values():

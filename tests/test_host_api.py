@@ -144,3 +144,42 @@ def test_no_cpu_fallback():
     from fdbm_amd.frontend import SpecFrontend
     with pytest.raises(RuntimeError):
         SpecFrontend()
+
+
+# ---- checkpoints (the reference's data format in front of the hot path) -------------------------------
+def test_param_order_matches_reference_fixture():
+    """tests/golden/param_order.json = named_parameters() order of the reference backbones
+    (tests/golden/make_param_order.py): torch_ema's shadow_params follow it."""
+    import json, os
+    from fdbm_amd.arch import Spec, VARIANTS
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "param_order.json")))
+    for name, keys in ref.items():
+        assert Spec(**VARIANTS[name]).param_order() == keys, name
+
+
+def test_lightning_checkpoint_import(tmp_path):
+    import torch
+    from fdbm_amd.arch import Spec, VARIANTS
+    from fdbm_amd.checkpoint import load_lightning_checkpoint
+    from fdbm_amd.weights import fill_state_dict
+    name = "ncsnpp_v2_5M"
+    spec = Spec(**VARIANTS[name])
+    raw = {k: torch.from_numpy(v) for k, v in fill_state_dict(spec.param_shapes(), seed=1).items()}
+    ema = {k: torch.from_numpy(v) for k, v in fill_state_dict(spec.param_shapes(), seed=2).items()}
+    ckpt = {
+        "state_dict": {"dnn." + k: v for k, v in raw.items()},
+        "hyper_parameters": {"backbone": name, "bridge": "sb", "noise_schedule": "bb", "n_fft": 512, "hop_length": 256},
+        "ema": {"decay": 0.999, "num_updates": 10, "shadow_params": [ema[k] for k in spec.param_order()], "collected_params": None},
+    }
+    path = tmp_path / "epoch=1.ckpt"
+    torch.save(ckpt, path)
+    hp, state = load_lightning_checkpoint(str(path))
+    assert hp["backbone"] == name and hp["bridge"] == "sb"
+    assert set(state) == set(raw) and all(torch.equal(state[k], ema[k]) for k in raw)          # EMA weights by default
+    _, state_raw = load_lightning_checkpoint(str(path), use_ema=False)
+    assert all(torch.equal(state_raw[k], raw[k]) for k in raw)
+    bad = dict(ckpt, ema={"shadow_params": ckpt["ema"]["shadow_params"][:-1]})
+    with pytest.raises(ValueError):
+        load_lightning_checkpoint(bad)
+    with pytest.raises(KeyError):
+        load_lightning_checkpoint({"hyper_parameters": {}})

@@ -1,0 +1,191 @@
+"""Folder enhancement driver - the caller of the hot path (mirror of the reference's infer_folder.py).
+
+  python -m fdbm_amd.infer --ckpt model.ckpt --test_dir noisy/ --enhanced_dir out/ [--N 30]
+         [--sampler_type ode_ei] [--sampler_kwargs "{...}"] [--keep_structure] [-D 0 1 2 ...]
+
+Same arguments and per-file procedure as infer_folder.py:69-148: load, resample to 16 kHz, normalise
+("noisy": peak, "std": standard deviation), STFT + compression + time padding, `bridge.sampler`,
+inverse transform, renormalise, clip to 0.95 if the peak exceeds 1, write.  One worker process per
+listed GPU over contiguous chunks of the sorted file list (infer_folder.py:150-230), no communication.
+
+Differences, all on the audio-file side (the image has neither soundfile / torchaudio nor librosa):
+WAV is read and written with scipy.io.wavfile (PCM 8/16/24/32-bit and float; output float32 like
+soundfile's default for float arrays would be 16-bit PCM - here float32 WAV, lossless), FLAC files are
+reported and skipped, and resampling uses scipy.signal.resample_poly (polyphase Kaiser FIR) instead of
+librosa's soxr - only for inputs that are not 16 kHz already.
+"""
+import argparse
+import ast
+import glob
+import os
+from os.path import basename, dirname, join
+
+import numpy as np
+import torch
+
+TARGET_SR = 16000
+
+
+def get_audio_files(test_dir):
+    """infer_folder.py:58-65 (same order: top-level first, then recursive; duplicates removed, order kept)."""
+    files = []
+    for pat in ("*.wav", join("**", "*.wav"), "*.flac", join("**", "*.flac")):
+        files += sorted(glob.glob(join(test_dir, pat), recursive=True))
+    seen, out = set(), []
+    for f in files:
+        if f not in seen:
+            seen.add(f)
+            out.append(f)
+    return out
+
+
+def read_wav(path):
+    """-> (float32 mono-or-multichannel array [C, L] in [-1, 1], sample rate)."""
+    from scipy.io import wavfile
+    sr, x = wavfile.read(path)
+    if x.dtype == np.int16:
+        x = x.astype(np.float32) / 32768.0
+    elif x.dtype == np.int32:
+        x = x.astype(np.float32) / 2147483648.0
+    elif x.dtype == np.uint8:
+        x = (x.astype(np.float32) - 128.0) / 128.0
+    else:
+        x = x.astype(np.float32)
+    x = x[None, :] if x.ndim == 1 else x.T
+    return np.ascontiguousarray(x), int(sr)
+
+
+def resample_to(x, sr, target=TARGET_SR):
+    if sr == target:
+        return x
+    from math import gcd
+    from scipy.signal import resample_poly
+    g = gcd(int(sr), int(target))
+    return resample_poly(x, target // g, sr // g, axis=-1).astype(np.float32)
+
+
+def write_wav(path, x, sr=TARGET_SR):
+    from scipy.io import wavfile
+    x = np.asarray(x, dtype=np.float32)
+    wavfile.write(path, sr, x.T if x.ndim == 2 else x)
+
+
+class Enhancer:
+    """Checkpoint -> callable(waveform [C, L] float32 at 16 kHz) -> enhanced waveform, on one GPU."""
+
+    def __init__(self, ckpt, device="cuda:0", N=30, sampler_type="ode_ei", sampler_kwargs=None,
+                 dtype=torch.bfloat16, use_ema=True):
+        from . import Bridge
+        from .checkpoint import backbone_from_checkpoint
+        from .frontend import SpecFrontend, pad_mode_for
+        self.device = torch.device(device)
+        self.net, hp = backbone_from_checkpoint(ckpt, dtype=dtype, device=device, use_ema=use_ema)
+        self.hp = hp
+        name = hp.get("backbone", "ncsnpp_v2")
+        self.pad_mode = pad_mode_for(name)
+        self.normalize = hp.get("normalize", "noisy")
+        # like BridgeModel (model.py:47-52) every scalar hyper-parameter is offered to the bridge, which keeps the
+        # ones it knows; N and sampler_type come from the command line (infer_folder.py:75-76)
+        bkw = {k: v for k, v in hp.items() if isinstance(v, (int, float, str, bool))
+               and k not in ("bridge", "backbone", "N", "sampler_type")}
+        self.bridge = Bridge(hp.get("bridge", "sb"), N=N, sampler_type=sampler_type, **bkw)
+        self.fe = SpecFrontend(n_fft=hp.get("n_fft", 510), hop_length=hp.get("hop_length", 128),
+                               window=hp.get("window", "hann"), spec_factor=hp.get("spec_factor", 0.15),
+                               spec_abs_exponent=hp.get("spec_abs_exponent", 0.5),
+                               transform_type=hp.get("transform_type", "exponent"), device=device)
+        self.sampler_kwargs = dict(sampler_kwargs or {})
+
+    @torch.no_grad()
+    def __call__(self, y):
+        y = torch.as_tensor(y, dtype=torch.float32)
+        if y.dim() == 1:
+            y = y[None]
+        T_orig = y.shape[-1]
+        if self.normalize == "std":
+            norm = y.std()
+        else:
+            norm = y.abs().max()
+        y = (y / norm).to(self.device)
+        Y = self.fe.spec_forward_padded(y, self.pad_mode)                 # [C,1,F,Tpad]; channels ride as the batch
+        sample = self.bridge.sampler(self.net, Y, **self.sampler_kwargs)
+        x_hat = self.fe.to_audio(sample[:, 0], T_orig) * norm.to(self.device)
+        peak = x_hat.abs().max()
+        if peak > 1.0:
+            x_hat = x_hat / peak * 0.95
+        return x_hat.cpu().numpy()
+
+
+def output_path(noisy_file, args):
+    if args.keep_structure:
+        return join(args.enhanced_dir, os.path.relpath(noisy_file, args.test_dir))
+    return join(args.enhanced_dir, basename(noisy_file))
+
+
+def enhance_files(gpu_id, file_list, args, counter=None):
+    """Worker: one GPU, its chunk of the file list (infer_folder.py:68-148).  Returns #files written."""
+    enh = Enhancer(args.ckpt, device=f"cuda:{gpu_id}", N=args.N, sampler_type=args.sampler_type,
+                   sampler_kwargs=args.sampler_kwargs, dtype=torch.float32 if args.fp32 else torch.bfloat16)
+    done = 0
+    for noisy_file in file_list:
+        try:
+            if noisy_file.lower().endswith(".flac"):
+                raise RuntimeError("FLAC input needs an audio library this build does not have; convert to WAV")
+            y, sr = read_wav(noisy_file)
+            x_hat = enh(resample_to(y, sr))
+            out = output_path(noisy_file, args)
+            os.makedirs(dirname(out) or ".", exist_ok=True)
+            write_wav(out, x_hat[0] if x_hat.shape[0] == 1 else x_hat)
+            done += 1
+        except Exception as e:      # like the reference: report, count, go on
+            print(f"\nError processing {noisy_file} on GPU {gpu_id}: {e}")
+        if counter is not None:
+            with counter.get_lock():
+                counter.value += 1
+    return done
+
+
+def enhance_folder(args):
+    from .dist import split_list
+    files = get_audio_files(args.test_dir)
+    if not files:
+        print(f"No audio files found in {args.test_dir}")
+        return 0
+    print(f"Found {len(files)} audio files")
+    os.makedirs(args.enhanced_dir, exist_ok=True)
+    gpus = [int(d) for d in args.device]
+    print(f"Using {len(gpus)} GPU(s): {','.join(map(str, gpus))}")
+    if len(gpus) == 1:
+        n = enhance_files(gpus[0], files, args)
+    else:
+        import torch.multiprocessing as mp
+        ctx = mp.get_context("spawn")
+        counter = ctx.Value("i", 0)
+        procs = []
+        for gpu, chunk in zip(gpus, split_list(files, len(gpus))):
+            if chunk:
+                p = ctx.Process(target=enhance_files, args=(gpu, chunk, args, counter))
+                p.start()
+                procs.append(p)
+        for p in procs:
+            p.join()
+        n = counter.value
+    print(f"Enhancement completed! Results saved to {args.enhanced_dir}")
+    return n
+
+
+def build_parser():
+    p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    p.add_argument("-D", "--device", default=["0"], nargs="+", help="GPU indices, e.g. 0 1 2 3")
+    p.add_argument("--test_dir", type=str, required=True)
+    p.add_argument("--enhanced_dir", type=str, required=True)
+    p.add_argument("--ckpt", type=str, required=True)
+    p.add_argument("--sampler_type", type=str, default="ode_ei")
+    p.add_argument("--sampler_kwargs", type=ast.literal_eval, default=None)
+    p.add_argument("--N", type=int, default=30)
+    p.add_argument("--keep_structure", action="store_true")
+    p.add_argument("--fp32", action="store_true", help="f32 parity mode instead of bf16 storage")
+    return p
+
+
+if __name__ == "__main__":
+    enhance_folder(build_parser().parse_args())

@@ -165,6 +165,41 @@ def test_graph_replay_survives_host_copies(golden):
         assert rel < 1e-1, rel
 
 
+def test_infer_folder_driver(tmp_path):
+    """The caller of the hot path (fdbm_amd.infer, mirror of infer_folder.py) end to end: synthetic Lightning
+    checkpoint with EMA weights, WAV files of two formats / rates in nested directories, --keep_structure."""
+    import argparse
+    from scipy.io import wavfile
+    from fdbm_amd import infer
+    name = "ncsnpp_v2_5M"
+    spec = Spec(**VARIANTS[name])
+    raw = {k: T(v) for k, v in fill_state_dict(spec.param_shapes(), seed=1).items()}
+    ema = {k: T(v) for k, v in fill_state_dict(spec.param_shapes(), seed=0).items()}
+    ckpt = tmp_path / "model.ckpt"
+    torch.save({"state_dict": {"dnn." + k: v for k, v in raw.items()},
+                "hyper_parameters": dict(backbone=name, bridge="sb", noise_schedule="bb", n_fft=512, hop_length=256,
+                                         window="sqrthann", spec_factor=0.15, spec_abs_exponent=0.5, normalize="noisy"),
+                "ema": {"shadow_params": [ema[k] for k in spec.param_order()]}}, ckpt)
+    rng = np.random.default_rng(0)
+    src = tmp_path / "noisy"
+    (src / "spk1").mkdir(parents=True)
+    a = (0.3 * rng.standard_normal(16000)).astype(np.float32)                       # 1 s, 16 kHz float
+    b = (8000 * rng.standard_normal(6000)).clip(-32768, 32767).astype(np.int16)     # 0.75 s, 8 kHz int16 -> resampled
+    wavfile.write(src / "a.wav", 16000, a)
+    wavfile.write(src / "spk1" / "b.wav", 8000, b)
+    out = tmp_path / "enhanced"
+    args = argparse.Namespace(device=["0"], test_dir=str(src), enhanced_dir=str(out), ckpt=str(ckpt), sampler_type="ode_ei",
+                              sampler_kwargs=None, N=3, keep_structure=True, fp32=False)
+    assert infer.enhance_folder(args) == 2
+    sr, ea = wavfile.read(out / "a.wav")
+    assert sr == 16000 and ea.shape == (16000,) and np.isfinite(ea).all() and np.abs(ea).max() <= 1.0
+    sr, eb = wavfile.read(out / "spk1" / "b.wav")
+    assert sr == 16000 and eb.shape == (12000,) and np.isfinite(eb).all()
+    # the driver is the documented pipeline and nothing else (and the bf16 path is reproducible)
+    enh = infer.Enhancer(str(ckpt), device=DEV, N=3)
+    assert np.array_equal(enh(a[None])[0], ea)
+
+
 def _toy_model(xt, y, t):
     tt = t.to(xt.device)[:, None, None, None]
     return 0.6 * y + 0.3 * xt * torch.cos(tt) + 0.05 * torch.roll(xt, 1, dims=-1)

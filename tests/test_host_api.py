@@ -183,3 +183,32 @@ def test_lightning_checkpoint_import(tmp_path):
         load_lightning_checkpoint(bad)
     with pytest.raises(KeyError):
         load_lightning_checkpoint({"hyper_parameters": {}})
+
+
+def test_infer_driver_file_side(tmp_path):
+    """fdbm_amd.infer without a GPU: file discovery order, WAV decoding of the PCM formats, resampling length,
+    output paths (infer_folder.py:58-65, 124-131)."""
+    import argparse
+    from scipy.io import wavfile
+    from fdbm_amd import infer
+    (tmp_path / "d" / "e").mkdir(parents=True)
+    x16 = (np.arange(800) % 100 * 300 - 15000).astype(np.int16)
+    wavfile.write(tmp_path / "d" / "b.wav", 8000, x16)
+    wavfile.write(tmp_path / "d" / "e" / "a.wav", 16000, np.stack([x16, -x16], 1))             # stereo
+    wavfile.write(tmp_path / "d" / "c.wav", 16000, (x16 / 32768.0).astype(np.float32))
+    files = infer.get_audio_files(str(tmp_path / "d"))
+    assert [os.path.relpath(f, tmp_path / "d") for f in files] == ["b.wav", "c.wav", os.path.join("e", "a.wav")]
+    y, sr = infer.read_wav(files[0])
+    assert sr == 8000 and y.shape == (1, 800) and y.dtype == np.float32 and abs(y[0, 0] + 15000 / 32768) < 1e-6
+    assert infer.resample_to(y, sr).shape == (1, 1600)
+    y2, _ = infer.read_wav(files[2])
+    assert y2.shape == (2, 800) and np.allclose(y2[0], -y2[1])
+    yf, _ = infer.read_wav(files[1])
+    assert np.allclose(yf[0], y[0], atol=1e-6)
+    args = argparse.Namespace(test_dir=str(tmp_path / "d"), enhanced_dir="/out", keep_structure=True)
+    assert infer.output_path(files[2], args) == os.path.join("/out", "e", "a.wav")
+    args.keep_structure = False
+    assert infer.output_path(files[2], args) == os.path.join("/out", "a.wav")
+    ns = infer.build_parser().parse_args(["--test_dir", "a", "--enhanced_dir", "b", "--ckpt", "c", "-D", "0", "1",
+                                          "--sampler_kwargs", "{'corrector': 'ald'}"])
+    assert ns.device == ["0", "1"] and ns.N == 30 and ns.sampler_type == "ode_ei" and ns.sampler_kwargs == {"corrector": "ald"}

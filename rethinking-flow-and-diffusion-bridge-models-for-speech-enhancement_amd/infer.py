@@ -1,7 +1,12 @@
-"""Folder enhancement driver - the caller of the hot path (mirror of the reference's infer_folder.py).
+"""Enhancement drivers - the callers of the hot path (mirror of the reference's infer_folder.py / infer_single.py).
 
   python -m fdbm_amd.infer --ckpt model.ckpt --test_dir noisy/ --enhanced_dir out/ [--N 30]
-         [--sampler_type ode_ei] [--sampler_kwargs "{...}"] [--keep_structure] [-D 0 1 2 ...]
+         [--sampler_type ode_ei] [--sampler_kwargs "{...}"] [--keep_structure] [-D 0 1 2 ...] [-C config.yaml]
+  python -m fdbm_amd.infer --ckpt model.ckpt --noisy_file a.wav [--output_file a_enhanced.wav] ...
+
+`-C file.yaml` reads the reference's config_infer_*.yaml files: `${key}` interpolation, `true` -> flag, null
+skipped, and - as in the reference, which appends them to sys.argv (infer_folder.py:41-55) - config values win
+over flags given on the command line.  The single-file mode clips to 0.5 instead of 0.95 (infer_single.py:99).
 
 Same arguments and per-file procedure as infer_folder.py:69-148: load, resample to 16 kHz, normalise
 ("noisy": peak, "std": standard deviation), STFT + compression + time padding, `bridge.sampler`,
@@ -96,7 +101,7 @@ class Enhancer:
         self.sampler_kwargs = dict(sampler_kwargs or {})
 
     @torch.no_grad()
-    def __call__(self, y):
+    def __call__(self, y, clip=0.95):
         y = torch.as_tensor(y, dtype=torch.float32)
         if y.dim() == 1:
             y = y[None]
@@ -111,7 +116,7 @@ class Enhancer:
         x_hat = self.fe.to_audio(sample[:, 0], T_orig) * norm.to(self.device)
         peak = x_hat.abs().max()
         if peak > 1.0:
-            x_hat = x_hat / peak * 0.95
+            x_hat = x_hat / peak * clip
         return x_hat.cpu().numpy()
 
 
@@ -173,11 +178,61 @@ def enhance_folder(args):
     return n
 
 
+def enhance_single(args):
+    """infer_single.py:60-106: one file, default output next to the input with an _enhanced suffix, clip to 0.5."""
+    enh = Enhancer(args.ckpt, device=f"cuda:{int(args.device[0])}", N=args.N, sampler_type=args.sampler_type,
+                   sampler_kwargs=args.sampler_kwargs, dtype=torch.float32 if args.fp32 else torch.bfloat16)
+    y, sr = read_wav(args.noisy_file)
+    x_hat = enh(resample_to(y, sr), clip=0.5)
+    out = args.output_file
+    if not out:
+        root, ext = os.path.splitext(args.noisy_file)
+        out = root + "_enhanced" + (ext or ".wav")
+    os.makedirs(dirname(out) or ".", exist_ok=True)
+    write_wav(out, x_hat[0] if x_hat.shape[0] == 1 else x_hat)
+    print(f"Enhanced audio saved to {out}")
+    return out
+
+
+def load_config(path):
+    """YAML with OmegaConf-style `${key}` interpolation (top-level keys, resolved recursively)."""
+    import re
+    import yaml
+    with open(path) as f:
+        cfg = yaml.safe_load(f) or {}
+
+    def resolve(v, depth=0):
+        if isinstance(v, str):
+            if depth > 20:
+                raise ValueError(f"cyclic interpolation in {path}")
+            return re.sub(r"\$\{([^}]+)\}", lambda m: str(resolve(cfg[m.group(1)], depth + 1)), v)
+        return v
+
+    return {k: resolve(v) for k, v in cfg.items()}
+
+
+def config_argv(cfg):
+    """The flags the reference would append to sys.argv for this config (infer_folder.py:41-55)."""
+    out = []
+    for k, v in cfg.items():
+        if v is None:
+            continue
+        if isinstance(v, bool):
+            if v:
+                out.append(f"--{k}")
+        else:
+            out += [f"--{k}", str(v)]
+    return out
+
+
 def build_parser():
     p = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    p.add_argument("-C", "--config", default=None, type=str, help="config_infer_folder.yaml / config_infer_single.yaml")
     p.add_argument("-D", "--device", default=["0"], nargs="+", help="GPU indices, e.g. 0 1 2 3")
-    p.add_argument("--test_dir", type=str, required=True)
-    p.add_argument("--enhanced_dir", type=str, required=True)
+    p.add_argument("--test_dir", type=str, default=None)
+    p.add_argument("--enhanced_dir", type=str, default=None)
+    p.add_argument("--noisy_file", type=str, default=None)
+    p.add_argument("--output_file", type=str, default=None)
     p.add_argument("--ckpt", type=str, required=True)
     p.add_argument("--sampler_type", type=str, default="ode_ei")
     p.add_argument("--sampler_kwargs", type=ast.literal_eval, default=None)
@@ -187,5 +242,23 @@ def build_parser():
     return p
 
 
+def parse_args(argv):
+    pre = argparse.ArgumentParser(add_help=False)
+    pre.add_argument("-C", "--config", default=None)
+    known, _ = pre.parse_known_args(argv)
+    if known.config:
+        argv = list(argv) + config_argv(load_config(known.config))      # appended: config wins, like the reference
+    args, _ = build_parser().parse_known_args(argv)                       # unknown config keys (version, exp_dir ...) ignored
+    if not args.noisy_file and not (args.test_dir and args.enhanced_dir):
+        raise SystemExit("give --noisy_file, or --test_dir and --enhanced_dir")
+    return args
+
+
+def main(argv=None):
+    import sys
+    args = parse_args(sys.argv[1:] if argv is None else argv)
+    return enhance_single(args) if args.noisy_file else enhance_folder(args)
+
+
 if __name__ == "__main__":
-    enhance_folder(build_parser().parse_args())
+    main()

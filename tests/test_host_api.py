@@ -212,3 +212,25 @@ def test_infer_driver_file_side(tmp_path):
     ns = infer.build_parser().parse_args(["--test_dir", "a", "--enhanced_dir", "b", "--ckpt", "c", "-D", "0", "1",
                                           "--sampler_kwargs", "{'corrector': 'ald'}"])
     assert ns.device == ["0", "1"] and ns.N == 30 and ns.sampler_type == "ode_ei" and ns.sampler_kwargs == {"corrector": "ald"}
+
+
+def test_infer_driver_config_files(tmp_path):
+    """-C config.yaml: ${} interpolation, booleans as flags, config wins over the command line
+    (infer_folder.py:41-55 appends the config to sys.argv), unknown keys ignored."""
+    from fdbm_amd import infer
+    cfg = tmp_path / "config_infer_folder.yaml"
+    cfg.write_text("test_dir: /data/noisy\nenhanced_dir: ${log_dir}/enhanced/${checkpoint}_sampler=${sampler_type}_N=${N}\n"
+                   "version: v7\ncheckpoint: last\nexp_dir: ./logs\nlog_dir: ${exp_dir}/${version}\n"
+                   "ckpt: ${log_dir}/checkpoints/${checkpoint}.ckpt\nN: 5\nsampler_type: ode_ei\n"
+                   "sampler_kwargs:\n  corrector_name: ald\n  snr: 0.5\nkeep_structure: true\nnothing: null\n")
+    c = infer.load_config(str(cfg))
+    assert c["ckpt"] == "./logs/v7/checkpoints/last.ckpt"
+    assert c["enhanced_dir"] == "./logs/v7/enhanced/last_sampler=ode_ei_N=5"
+    args = infer.parse_args(["-C", str(cfg), "--N", "30", "--ckpt", "x.ckpt", "-D", "0", "1"])
+    assert args.N == 5 and args.ckpt == "./logs/v7/checkpoints/last.ckpt"      # the config wins
+    assert args.keep_structure and args.sampler_kwargs == {"corrector_name": "ald", "snr": 0.5}
+    assert args.test_dir == "/data/noisy" and args.device == ["0", "1"]
+    single = infer.parse_args(["--ckpt", "m.ckpt", "--noisy_file", "a.wav"])
+    assert single.noisy_file == "a.wav" and single.output_file is None and single.N == 30
+    with pytest.raises(SystemExit):
+        infer.parse_args(["--ckpt", "m.ckpt"])

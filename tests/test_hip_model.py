@@ -143,6 +143,21 @@ def test_sampler_batched_and_graph_equals_eager(golden):
     assert (a.cpu() - T(g["mini64_sb_bb_ode_ei_N3"])).abs().max() < 4e-3
 
 
+def test_batch_rows_are_independent():
+    """Samples of a batch never mix (GroupNorm and attention are per sample): evaluating [a, b] gives, row by
+    row, what evaluating [a] and [b] gives - up to rounding, because the kernel / tile choice depends on the
+    batch size.  Full-size map (257 x 256), f32 mode."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.view_as_complex(torch.randn(2, 1, 257, 256, 2, generator=g)).to(DEV)
+    y = torch.view_as_complex(torch.randn(2, 1, 257, 256, 2, generator=g)).to(DEV)
+    t = torch.tensor([0.8, 0.3])
+    m = net("ncsnpp_v2_5M")
+    both = m(x, y, t.to(DEV)).cpu()
+    for i in range(2):
+        one = m(x[i:i + 1], y[i:i + 1], t[i:i + 1].to(DEV)).cpu()
+        assert (both[i:i + 1] - one).abs().max() < 5e-5 * max(1.0, one.abs().max().item())
+
+
 def test_graph_replay_survives_host_copies(golden):
     """Regression: a synchronous device-to-host copy between two replays of the sampler graph (what a caller
     that fetches the spectrogram, or a host-side gather, does) used to leave the runtime's memset node inside

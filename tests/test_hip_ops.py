@@ -363,6 +363,28 @@ def test_conv_igemm(case, dtype, splitk, conv_kernels):
     assert err < tol, (name, err)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_full_size_linearity(dtype):
+    """BASELINE's full map (256 x 256 x 128 -> 128, the halo-patch kernel's home): too big for a torch CPU
+    reference in a unit test, so a size-independent property - scaling the input by a power of two scales every
+    product and every partial sum exactly, hence conv(4x) == 4 conv(x) and conv(x/2) == conv(x)/2 BITWISE
+    (no bias) - plus a spot check of 64 output pixels against torch."""
+    B, H, W, cin, cout = 1, 256, 256, 128, 128
+    x = rnd(B, cin, H, W, seed=11)
+    w = rnd(cout, cin, 3, 3, seed=21) / math.sqrt(cin * 9)
+    o1, _, _ = run_conv([(x, 9)], [w], None, dtype)
+    o4, _, _ = run_conv([(4.0 * x, 9)], [w], None, dtype)
+    oh, _, _ = run_conv([(0.5 * x, 9)], [w], None, dtype)
+    assert torch.equal(o4, 4.0 * o1) and torch.equal(oh, 0.5 * o1)
+    q = lambda t: t.to(dtype).float()
+    ys, xs = torch.randint(1, H - 1, (64,), generator=torch.Generator().manual_seed(0)), \
+        torch.randint(1, W - 1, (64,), generator=torch.Generator().manual_seed(1))
+    for yy, xx in zip(ys.tolist(), xs.tolist()):
+        ref = (q(x)[0, :, yy - 1:yy + 2, xx - 1:xx + 2][None] * q(w)).sum((1, 2, 3))
+        tol = 2e-5 if dtype == torch.float32 else 2e-2
+        assert (o1[0, :, yy, xx] - ref).abs().max() < tol
+
+
 FUSED_CASES = [
     # name, B, H, W, cins, cout, G_in, G_out, shortcut, comb
     ("blk_16x16", 2, 16, 16, [256], 256, 32, 32, False, False),

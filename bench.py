@@ -13,9 +13,12 @@ Workload at every N (weak scaling): BASELINE.json configs[1] per rank - one synt
 4 s clip, ncsnpp_v2 (65.6 M parameters, deterministic synthetic weights), bridge sb/bb,
 bf16 storage + fp32 accumulate.  --batch 64 gives configs[2].
 
-Rank 0 prints ONE JSON line.  `roofline` prices the dominant kernel (conv_igemm_kernel,
-MFMA-bound) from HIP-event timings of every conv launch of one forward; `cpu_baseline`
-times the CPU oracle (a port, oracle/) on a bounded sample on the host cores.
+Rank 0 prints ONE JSON line.  `roofline` prices conv_patch_kernel (MFMA-bound, 65 % of the
+algorithmic flops) from HIP-event timings of its launches in one eager forward, lists every
+convolution kernel family the same way (`families`) and carries the HBM bytes per launch
+measured offline with rocprofv3 PMC passes (profiles/r01/e_pmc_traffic_b1_bf16.json);
+`cpu_baseline` times the CPU oracle (a port, oracle/) on a bounded sample on the host cores.
+FDBM_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks.
 """
 import argparse
 import json

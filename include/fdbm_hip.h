@@ -139,6 +139,10 @@ int fdbm_resample2x_units(void* out_plain, void* out_act, const void* in, const 
                           int nsplit, int stat_units, int64_t count, float eps, const float* gamma,
                           const float* beta, int B, int H, int W, int C, int G, int up, int dtype,
                           void* stream);
+/* the progressive-input pyramid (ncsnpp_v2.py:296-305) in one launch: outs[l] = downsample_2d applied l+1
+ * times to `in` (f32 [B][H][W][4]); outs = HOST array of `levels` device pointers, level l is
+ * [B][H>>(l+1)][W>>(l+1)][4].  Same arithmetic as `levels` chained fdbm_resample2x calls. */
+int fdbm_pyramid_down_chain(const float* in, void* const* outs, int levels, int B, int H, int W, void* stream);
 
 /* ------------------------------------------------------------------ convolution (implicit GEMM on MFMA)
  * nn.Conv2d 3x3 pad 1 / 1x1 (layers.py:100-105,118-124) and NIN (layers.py:546-555) as one
@@ -308,6 +312,7 @@ typedef struct {
 #define FDBM_OP_FORK 15        /* iarg: event id */
 #define FDBM_OP_MARK 16        /* iarg: event id */
 #define FDBM_OP_JOIN 17        /* iarg: event id */
+#define FDBM_OP_PYRDOWN 18     /* iarg: in, levels, B, H, W, out[0..7] */
 #define FDBM_MAX_EVENTS 64
 
 /* creates the side stream and FDBM_MAX_EVENTS events once per process (call it outside graph capture;

@@ -227,6 +227,60 @@ __global__ void __launch_bounds__(256) resample2x_tile_kernel(
   }
 }
 
+// The whole progressive-input pyramid in ONE launch: level l+1 = downsample_2d(level l) of the 4-channel f32
+// network input (ncsnpp_v2.py:296-305), 6 levels for the 7-level net.  One workgroup per image walks the
+// levels (a workgroup barrier between them: every level is read only by the workgroup that wrote it); the
+// per-level launches it replaces were pure launch floor (6 x ~9 us for < 1 MB of data).  Tap order of
+// resample2x_kernel (bit-identical results).
+struct PyrPtrs { float* out[8]; };
+
+__global__ void __launch_bounds__(1024) pyramid_down_chain_kernel(const float* __restrict__ in, PyrPtrs ptrs,
+                                                                  int levels, int H, int W) {
+  const int b = blockIdx.x;
+  const float* src = in + (int64_t)b * H * W * 4;
+  int h = H, w = W;
+  for (int l = 0; l < levels; ++l) {
+    const int oh = h / 2, ow = w / 2;
+    float* dst = ptrs.out[l] + (int64_t)b * oh * ow * 4;
+    for (int i = threadIdx.x; i < oh * ow; i += blockDim.x) {
+      const int oy = i / ow, ox = i - oy * ow;
+      const float w4[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int iy = 2 * oy - 1 + a;
+        if (iy < 0 || iy >= h) continue;
+#pragma unroll
+        for (int bx = 0; bx < 4; ++bx) {
+          const int ix = 2 * ox - 1 + bx;
+          if (ix < 0 || ix >= w) continue;
+          const float wgt = w4[a] * w4[bx];
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((int64_t)iy * w + ix) * 4);
+          acc[0] += wgt * v[0]; acc[1] += wgt * v[1]; acc[2] += wgt * v[2]; acc[3] += wgt * v[3];
+        }
+      }
+      *reinterpret_cast<f32x4*>(dst + (int64_t)i * 4) = acc;
+    }
+    __threadfence_block();
+    __syncthreads();
+    src = dst;
+    h = oh; w = ow;
+  }
+}
+
+extern "C" int fdbm_pyramid_down_chain(const float* in, void* const* outs, int levels, int B, int H, int W,
+                                       void* stream) {
+  FDBM_CHECK(in && outs && levels >= 1 && levels <= 8, "fdbm_pyramid_down_chain: bad arguments (levels=%d)", levels);
+  FDBM_CHECK(B > 0 && H % (1 << levels) == 0 && W % (1 << levels) == 0,
+             "fdbm_pyramid_down_chain: H, W (%d x %d) must be divisible by 2^levels", H, W);
+  PyrPtrs ptrs;
+  for (int l = 0; l < 8; ++l) ptrs.out[l] = l < levels ? (float*)outs[l] : nullptr;
+  for (int l = 0; l < levels; ++l) FDBM_CHECK(ptrs.out[l], "fdbm_pyramid_down_chain: null output %d", l);
+  pyramid_down_chain_kernel<<<B, 1024, 0, (hipStream_t)stream>>>(in, ptrs, levels, H, W);
+  FDBM_LAUNCH_CHECK("fdbm_pyramid_down_chain");
+  return 0;
+}
+
 extern "C" int fdbm_resample2x(void* out_plain, void* out_act, const void* in, const float* stats,
                                int nsplit, int64_t count, float eps,
                                const float* gamma, const float* beta, int B, int H, int W, int C,

@@ -153,6 +153,12 @@ extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* main_stream
       case FDBM_OP_MEMSET:
         rc = fdbm_memset_zero(P(0), o.iarg[1], stream);
         break;
+      case FDBM_OP_PYRDOWN: {
+        void* outs[8];
+        for (int l = 0; l < 8; ++l) outs[l] = P(5 + l);
+        rc = fdbm_pyramid_down_chain(CFP(0), outs, I(1), I(2), I(3), I(4), stream);
+        break;
+      }
       default:
         fdbm_set_error("fdbm_run_program: unknown opcode %d at op %d", o.opcode, k);
         return 3;

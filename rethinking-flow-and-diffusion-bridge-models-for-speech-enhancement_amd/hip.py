@@ -51,7 +51,7 @@ class Op(ctypes.Structure):
 
 
 OP_CONV, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_RESAMPLE, OP_COMBINE, OP_ATTENTION, \
-    OP_STEM, OP_PACK, OP_UNPACK, OP_TEMB, OP_DENSE, OP_UPDATE, OP_MEMSET, OP_FORK, OP_MARK, OP_JOIN = range(1, 18)
+    OP_STEM, OP_PACK, OP_UNPACK, OP_TEMB, OP_DENSE, OP_UPDATE, OP_MEMSET, OP_FORK, OP_MARK, OP_JOIN, OP_PYRDOWN = range(1, 19)
 
 # name -> (argtypes without the trailing stream)
 _SIGS = {
@@ -63,6 +63,7 @@ _SIGS = {
     "fdbm_temb": [c_void_p] * 8 + [c_int] * 2,
     "fdbm_dense_rows": [c_void_p] * 4 + [c_int] * 3,
     "fdbm_copy_f32": [c_void_p, c_void_p, c_i64],
+    "fdbm_pyramid_down_chain": [c_void_p, c_void_p, c_int, c_int, c_int, c_int],
     "fdbm_conv_stem": [c_void_p] * 4 + [c_int] * 5,
     "fdbm_conv_stem_stats": [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_int],
     "fdbm_gn_stats": [c_void_p, c_void_p, c_int, c_void_p, c_int] + [c_int] * 5,

@@ -544,9 +544,23 @@ class Program:
         self.fork()
         self.lane = 1
         pyr_levels = [inp]
-        for _ in range(spec.num_resolutions - 1):
+        nlv = spec.num_resolutions - 1
+        # the two large levels as ordinary (many-workgroup) launches, the small rest chained in ONE launch by one
+        # workgroup per image (there the per-level launches are pure launch floor)
+        big = min(2, nlv)
+        for _ in range(big):
             pd_, _ = self.resample(pyr_levels[-1], False)
             pyr_levels.append(pd_)
+        rest = nlv - big
+        if rest >= 1 and Fn % (1 << nlv) == 0 and T % (1 << nlv) == 0:
+            h0, w0 = Fn >> big, T >> big
+            for l in range(rest):
+                pyr_levels.append(self.new_act(h0 >> (l + 1), w0 >> (l + 1), IN_CH, torch.float32))
+            self.emit(hip.OP_PYRDOWN, [pyr_levels[big].ptr, rest, B, h0, w0] + [a_.ptr for a_ in pyr_levels[big + 1:]] + [0] * (8 - rest))
+        else:
+            for _ in range(rest):
+                pd_, _ = self.resample(pyr_levels[-1], False)
+                pyr_levels.append(pd_)
         ev_pyr = self.mark()
         self.lane = 0
         stem = nxt()

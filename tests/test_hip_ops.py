@@ -191,6 +191,27 @@ def test_resample2x(dtype, tol, up, shape):
         assert (nchw(o) - fn(p)).abs().max() < 1e-6
 
 
+def test_pyramid_down_chain():
+    """All levels of the progressive-input pyramid in one launch == chained fdbm_resample2x calls (bitwise) ==
+    the oracle's downsample_2d applied repeatedly."""
+    import ctypes
+    B, H, W, L = 2, 64, 128, 4
+    p = rnd(B, 4, H, W, seed=6)
+    d = nhwc(p)
+    outs = [torch.empty(B, H >> (l + 1), W >> (l + 1), 4, device=DEV) for l in range(L)]
+    arr = (ctypes.c_void_p * L)(*[o.data_ptr() for o in outs])
+    hip.call("fdbm_pyramid_down_chain", hip.ptr(d), ctypes.cast(arr, ctypes.c_void_p), L, B, H, W)
+    torch.cuda.synchronize()
+    cur, ref = d, p
+    for l in range(L):
+        nxt = torch.empty_like(outs[l])
+        hip.call("fdbm_resample2x", hip.ptr(nxt), 0, hip.ptr(cur), 0, 0, 0, 0.0, 0, 0, B, H >> l, W >> l, 4, 0, 0, hip.F32)
+        ref = onet.downsample_2d(ref)
+        assert torch.equal(outs[l], nxt), l
+        assert (nchw(outs[l]) - ref).abs().max() < 1e-6
+        cur = nxt
+
+
 def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=None, scale=1.0, splitk=False,
              gn=None, comb=None, stat_G=0, res_up=None):
     """segs_nchw: list of (x NCHW cpu tensor, taps); weights: list of W [Cout, cin, k, k] per seg."""

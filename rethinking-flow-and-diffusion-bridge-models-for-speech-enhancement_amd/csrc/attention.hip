@@ -249,6 +249,137 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(bf16_t* __restrict_
     }
 }
 
+// The benchmark shape (N = 256 tokens, C = 256 channels: the 16 x 16 level of a 4 s clip) as a fully unrolled
+// variant: the kernel above pays one exposed memory round trip per 64-key tile (9 of them); here every load of
+// Q, K and V is requested up front (33 x 16 B per thread, 512 threads), so the 16 workgroups pay ONE round trip
+// and then only LDS phases.  8 waves: 16 keys each of a 128-key tile for the scores, 32 channels each for P.V.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attention_mfma256_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ qkv,
+                                                                float scale) {
+  constexpr int N = 256, C = 256;
+  constexpr int KRS = C * 2 + 16;             // K-tile / Q-tile row stride (bytes)
+  constexpr int VRS = 64 * 2 + 16;            // V^T-tile row stride
+  constexpr int PRS = N * 2 + 16;             // P row stride
+  constexpr int KV_BYTES = 128 * KRS;         // 67,584 (>= C * VRS = 36,864)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+  unsigned char* s_kv = smem_b;
+  float* s_S = reinterpret_cast<float*>(smem_b + KV_BYTES);                 // [16][N]
+  unsigned char* s_P = smem_b + KV_BYTES + 16 * N * 4;                      // [16][PRS]
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fk = lane >> 4;
+  const bf16_t* base = qkv + (int64_t)b * N * 3 * C;
+  const int r32 = tid >> 5, ch = tid & 31;    // this thread's row-within-16 and 16-byte chunk for K / V items
+
+  // ---- every global load of the kernel --------------------------------------------------------------------
+  const uint4 qreg = *reinterpret_cast<const uint4*>(base + (int64_t)(q0 + r32) * 3 * C + ch * 8);       // 16 queries x 32 chunks
+  // (named scalars, not arrays: a 64-dword array is left in scratch memory by this compiler even with constant
+  // indices; key r32 + 16 j for kreg_j, key pair r32 + 16 j - keys 2 kp, 2 kp + 1 - for vlo_j / vhi_j)
+#define KLOAD(j) const uint4 kreg_##j = *reinterpret_cast<const uint4*>(base + (int64_t)(r32 + 16 * (j)) * 3 * C + C + ch * 8);
+  KLOAD(0) KLOAD(1) KLOAD(2) KLOAD(3) KLOAD(4) KLOAD(5) KLOAD(6) KLOAD(7)
+  KLOAD(8) KLOAD(9) KLOAD(10) KLOAD(11) KLOAD(12) KLOAD(13) KLOAD(14) KLOAD(15)
+#undef KLOAD
+#define VLOAD(j)                                                                                                  \
+  const uint4 vlo_##j = *reinterpret_cast<const uint4*>(base + (int64_t)(2 * (r32 + 16 * (j))) * 3 * C + 2 * C + ch * 8);      \
+  const uint4 vhi_##j = *reinterpret_cast<const uint4*>(base + (int64_t)(2 * (r32 + 16 * (j)) + 1) * 3 * C + 2 * C + ch * 8);
+  VLOAD(0) VLOAD(1) VLOAD(2) VLOAD(3) VLOAD(4) VLOAD(5) VLOAD(6) VLOAD(7)
+#undef VLOAD
+
+  // ---- Q tile -> LDS -> operand registers ------------------------------------------------------------------
+  *reinterpret_cast<uint4*>(s_kv + r32 * KRS + ch * 16) = qreg;
+  __syncthreads();
+  uint4 qf[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) qf[ks] = *reinterpret_cast<const uint4*>(s_kv + frow * KRS + (ks * 4 + fk) * 16);
+  __syncthreads();
+
+  // ---- scores, two tiles of 128 keys -------------------------------------------------------------------------
+  // (tile bodies as macros with literal tile indices: with a run-time index, or captured by a lambda, the
+  // register arrays end up in scratch memory)
+#define KSTORE(jj, reg) *reinterpret_cast<uint4*>(s_kv + (r32 + 16 * (jj)) * KRS + ch * 16) = reg;
+#define SCORE_TILE(kt, K0, K1, K2, K3, K4, K5, K6, K7)                                                                                             \
+  {                                                                                                                \
+    KSTORE(0, K0) KSTORE(1, K1) KSTORE(2, K2) KSTORE(3, K3) KSTORE(4, K4) KSTORE(5, K5) KSTORE(6, K6) KSTORE(7, K7)     \
+    __syncthreads();                                                                                               \
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};                                                                              \
+    _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                             \
+      const uint4 kf = *reinterpret_cast<const uint4*>(s_kv + (wave * 16 + frow) * KRS + (ks * 4 + fk) * 16);      \
+      Mfma<bf16_t>::run(kf, qf[ks], acc);                                                                          \
+    }                                                                                                              \
+    *reinterpret_cast<f32x4*>(s_S + frow * N + (kt) * 128 + wave * 16 + fk * 4) = acc * scale;                     \
+    __syncthreads();                                                                                               \
+  }
+  SCORE_TILE(0, kreg_0, kreg_1, kreg_2, kreg_3, kreg_4, kreg_5, kreg_6, kreg_7)
+  SCORE_TILE(1, kreg_8, kreg_9, kreg_10, kreg_11, kreg_12, kreg_13, kreg_14, kreg_15)
+#undef SCORE_TILE
+#undef KSTORE
+
+  // ---- softmax: 32 threads per query, 8 keys each -------------------------------------------------------------
+  {
+    const int q = tid >> 5, part = tid & 31;
+    const float* row = s_S + q * N + part * 8;
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = row[i];
+    float m = v[0];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) m = fmaxf(m, v[i]);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v[i] = __expf(v[i] - m); l += v[i]; }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) l += __shfl_xor(l, off);
+    const float inv = 1.0f / l;
+    bf16x8 pv;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) pv[i] = (bf16_t)(v[i] * inv);
+    *reinterpret_cast<bf16x8*>(s_P + q * PRS + part * 16) = pv;
+  }
+  __syncthreads();
+
+  // ---- O = P . V: wave w owns channels [32 w, 32 w + 32), four tiles of 64 keys -------------------------------
+  f32x4 oacc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#define VT_ITEM(jj, LO, HI)                                                                                        \
+  {                                                                                                                \
+    const int kp = r32 + 16 * (jj);                                                                                \
+    const unsigned lw[4] = {LO.x, LO.y, LO.z, LO.w}, hw[4] = {HI.x, HI.y, HI.z, HI.w};                             \
+    const int slot = (kp >> 2) ^ (ch & 7);                                                                         \
+    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                                \
+      const unsigned le = (e & 1) ? (lw[e >> 1] >> 16) : (lw[e >> 1] & 0xffffu);                                   \
+      const unsigned he = (e & 1) ? (hw[e >> 1] & 0xffff0000u) : (hw[e >> 1] << 16);                               \
+      *reinterpret_cast<unsigned*>(s_kv + (ch * 8 + e) * VRS + slot * 16 + (kp & 3) * 4) = le | he;                \
+    }                                                                                                              \
+  }
+#define PV_TILE(kt, L0, H0, L1, H1)                                                                                \
+  {                                                                                                                \
+    VT_ITEM(0, L0, H0)                                                                                             \
+    VT_ITEM(1, L1, H1)                                                                                             \
+    __syncthreads();                                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                             \
+      const uint4 pf = *reinterpret_cast<const uint4*>(s_P + frow * PRS + ((kt) * 64 + ks * 32 + fk * 8) * 2);     \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
+        const int c = (wave * 2 + j) * 16 + frow;                                                                  \
+        const uint4 vf = *reinterpret_cast<const uint4*>(s_kv + c * VRS + (((ks * 4 + fk) ^ ((c >> 3) & 7)) << 4)); \
+        Mfma<bf16_t>::run(vf, pf, oacc[j]);                                                                        \
+      }                                                                                                            \
+    }                                                                                                              \
+    __syncthreads();                                                                                               \
+  }
+  PV_TILE(0, vlo_0, vhi_0, vlo_1, vhi_1) PV_TILE(1, vlo_2, vhi_2, vlo_3, vhi_3)
+  PV_TILE(2, vlo_4, vhi_4, vlo_5, vhi_5) PV_TILE(3, vlo_6, vhi_6, vlo_7, vhi_7)
+#undef PV_TILE
+#undef VT_ITEM
+  bf16_t* dst = out + ((int64_t)b * N + q0 + frow) * C;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int c = (wave * 2 + j) * 16 + fk * 4;
+    const bf16x4 t = {(bf16_t)oacc[j][0], (bf16_t)oacc[j][1], (bf16_t)oacc[j][2], (bf16_t)oacc[j][3]};
+    *reinterpret_cast<bf16x4*>(dst + c) = t;
+  }
+}
+
 extern "C" int fdbm_attention(void* out, const void* qkv, int B, int N, int C, int dtype, void* stream) {
   FDBM_CHECK(out && qkv, "fdbm_attention: null pointer");
   FDBM_CHECK(C % 8 == 0 && C <= 256, "fdbm_attention: C=%d must be a multiple of 8, <= 256", C);
@@ -257,7 +388,12 @@ extern "C" int fdbm_attention(void* out, const void* qkv, int B, int N, int C, i
   dim3 grid(cdiv(N, ATT_QB), B);
   const float scale = 1.0f / sqrtf((float)C);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FDBM_BF16 && N % 64 == 0 && N <= 1024 && C % 64 == 0) {
+  if (dtype == FDBM_BF16 && N == 256 && C == 256) {
+    const size_t sm = (size_t)128 * (256 * 2 + 16) + (size_t)16 * 256 * 4 + (size_t)16 * (256 * 2 + 16);
+    static bool set256 = false;
+    if (!set256) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); set256 = true; }
+    attention_mfma256_kernel<<<dim3(N / 16, B), 512, sm, st>>>((bf16_t*)out, (const bf16_t*)qkv, scale);
+  } else if (dtype == FDBM_BF16 && N % 64 == 0 && N <= 1024 && C % 64 == 0) {
     const int krs = C * 2 + 16;
     const size_t kv = (size_t)(64 * krs > C * 144 ? 64 * krs : C * 144);
     const size_t sm = kv + (size_t)16 * N * 4 + (size_t)16 * (N * 2 + 16);

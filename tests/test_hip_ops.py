@@ -191,6 +191,23 @@ def test_resample2x(dtype, tol, up, shape):
         assert (nchw(o) - fn(p)).abs().max() < 1e-6
 
 
+def test_memset_and_copy_kernels():
+    """fdbm_memset_zero / fdbm_copy_f32: the library's own kernels for what would otherwise be runtime memset /
+    memcpy nodes inside the replayed graphs (tail bytes, neighbours untouched)."""
+    for nbytes in (0, 16, 100, 4096 + 7, 3 << 20):
+        buf = torch.full((nbytes + 64,), 0xAB, dtype=torch.uint8, device=DEV)
+        base = buf[16:]                                   # 16-byte aligned start inside a larger buffer
+        assert base.data_ptr() % 16 == 0
+        hip.call("fdbm_memset_zero", hip.ptr(base), nbytes)
+        torch.cuda.synchronize()
+        assert not base[:nbytes].any() and (buf[:16] == 0xAB).all() and (base[nbytes:] == 0xAB).all()
+    src = torch.randn(100003, device=DEV)
+    dst = torch.zeros(100003 + 5, device=DEV)
+    hip.call("fdbm_copy_f32", hip.ptr(dst), hip.ptr(src), src.numel())
+    torch.cuda.synchronize()
+    assert torch.equal(dst[:-5], src) and not dst[-5:].any()
+
+
 def test_pyramid_down_chain():
     """All levels of the progressive-input pyramid in one launch == chained fdbm_resample2x calls (bitwise) ==
     the oracle's downsample_2d applied repeatedly."""

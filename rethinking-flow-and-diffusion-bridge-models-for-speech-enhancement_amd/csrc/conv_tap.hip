@@ -111,29 +111,59 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
 
   auto seg_nch = [&](int s) __attribute__((always_inline)) { return (SEG_FIELD(p, s, cin) + KC - 1) / KC; };
 
-  // ---- patch staging (as conv_patch.hip), two register sets: the patch of chunk c+2 is in flight
-  // while chunk c computes and chunk c+1's patch is transformed and written ----------------------------
-  uint4 pregA[NPL], pregB[NPL];
-  int pgcbA = -1, pgcbB = -1;
-  bool pcokA = true, pcokB = true;
-  auto load_patch = [&](auto SET, int s, int c) __attribute__((always_inline)) {
+  // ---- register sets ----------------------------------------------------------------------------------
+  // The loop is a chain of short chunks whose operands come from L2 / HBM (weights: read once per forward;
+  // the patch: the previous kernel's output): a chunk can start no earlier than its loads land, so the chunk
+  // time is (memory latency) / (chunks in flight).  D register sets hold the patch items and the weight
+  // fragments of the chunks c .. c+D-1; set c % D is reloaded with chunk c+D as soon as chunk c has consumed
+  // it.  D = 4 where a set is small (one n-tile: the small maps, where the chain is the whole run time),
+  // D = 2 for the wide tiles, whose MFMA work per chunk covers the latency.
+  // Named sets A-D selected by `if constexpr` (an array of sets would be indexed through scratch memory).
+  constexpr int D = (NT == 1) ? 4 : 2;
+#define SET_PUT(S, lhsA, lhsB, lhsC, lhsD, val)                                                   \
+  do {                                                                                           \
+    if constexpr ((S) == 0) lhsA = (val); else if constexpr ((S) == 1) lhsB = (val);              \
+    else if constexpr ((S) == 2) lhsC = (val); else lhsD = (val);                                 \
+  } while (0)
+#define SET_GET(S, a, b, c, d) ((S) == 0 ? (a) : (S) == 1 ? (b) : (S) == 2 ? (c) : (d))
+  [[maybe_unused]] uint4 pregA[NPL], pregB[NPL], pregC[NPL], pregD[NPL];
+  [[maybe_unused]] int pgcbA = 0, pgcbB = 0, pgcbC = 0, pgcbD = 0;               // first GN table entry of the thread's 16 bytes
+  [[maybe_unused]] bool pgnA = false, pgnB = false, pgnC = false, pgnD = false;  // wave-uniform: the segment is normalised
+  [[maybe_unused]] bool pcokA = true, pcokB = true, pcokC = true, pcokD = true;  // channel chunk inside the segment
+  [[maybe_unused]] bool t9A = true, t9B = true, t9C = true, t9D = true;          // wave-uniform: a 9-tap chunk
+  // ---- load cursor: the next chunk to fetch ----------------------------------------------------------------
+  // The fields of its segment live in scalars that change only when the cursor enters a new segment: p.seg[s]
+  // with a run-time s is a chain of dependent scalar memory loads from the kernel argument (measured: ~0.5 us
+  // of every chunk went into them).
+  const void* L_src = p.seg[0].src;
+  int L_C = p.seg[0].C, L_coff = p.seg[0].coff, L_cin = p.seg[0].cin, L_taps = p.seg[0].taps;
+  int L_gn = GNP ? p.seg_gn[0] : -1;
+  int L_nch = (L_cin + KC - 1) / KC;
+  int L_s = 0, L_c = 0, L_kb = 0;
+  auto enter_seg = [&](int sn) __attribute__((always_inline)) {
+    L_src = SEG_FIELD(p, sn, src);
+    L_C = SEG_FIELD(p, sn, C); L_coff = SEG_FIELD(p, sn, coff); L_cin = SEG_FIELD(p, sn, cin); L_taps = SEG_FIELD(p, sn, taps);
+    if constexpr (GNP) L_gn = sn == 0 ? p.seg_gn[0] : sn == 1 ? p.seg_gn[1] : sn == 2 ? p.seg_gn[2] : p.seg_gn[3];
+    L_nch = (L_cin + KC - 1) / KC;
+  };
+  auto advance = [&]() __attribute__((always_inline)) {          // (stays on the conv's last chunk)
+    if (L_c + 1 < L_nch) { ++L_c; }
+    else if (L_s + 1 < p.nseg) { L_kb += L_taps * L_nch; ++L_s; L_c = 0; enter_seg(L_s); }
+  };
+  auto load_patch = [&](auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    const void* sg_src = SEG_FIELD(p, s, src);
-    const int sg_C = SEG_FIELD(p, s, C), sg_coff = SEG_FIELD(p, s, coff), sg_cin = SEG_FIELD(p, s, cin);
-    const int cvalid = min(KC, sg_cin - c * KC);
+    const int cvalid = min(KC, L_cin - L_c * KC);
     const bool ok = pchunk * VW < cvalid;
-    const T* src = reinterpret_cast<const T*>(sg_src) + img * sg_C + sg_coff + (ok ? c * KC + pchunk * VW : 0);
+    const T* src = reinterpret_cast<const T*>(L_src) + img * L_C + L_coff + (ok ? L_c * KC + pchunk * VW : 0);
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
-      const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)ppix[j] * sg_C);
-      if constexpr (S == 0) pregA[j] = v; else pregB[j] = v;
+      const uint4 v = *reinterpret_cast<const uint4*>(src + (int64_t)ppix[j] * L_C);
+      SET_PUT(S, pregA[j], pregB[j], pregC[j], pregD[j], v);
     }
-    int cb = -1;
-    if constexpr (GNP) {
-      const int sgn = s == 0 ? p.seg_gn[0] : s == 1 ? p.seg_gn[1] : s == 2 ? p.seg_gn[2] : p.seg_gn[3];
-      cb = sgn >= 0 ? sgn + c * KC + pchunk * VW : -1;
-    }
-    if constexpr (S == 0) { pcokA = ok; pgcbA = cb; } else { pcokB = ok; pgcbB = cb; }
+    SET_PUT(S, pcokA, pcokB, pcokC, pcokD, ok);
+    SET_PUT(S, pgcbA, pgcbB, pgcbC, pgcbD, max(L_gn, 0) + L_c * KC + pchunk * VW);
+    SET_PUT(S, pgnA, pgnB, pgnC, pgnD, L_gn >= 0);
+    SET_PUT(S, t9A, t9B, t9C, t9D, L_taps == 9);
   };
   // transform (GroupNorm scale/shift + SiLU) and store ONE patch item: issued between the MFMA groups of
   // a chunk so that its VALU work runs beside them
@@ -142,12 +172,12 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
     constexpr int j = decltype(JJ)::value;
     if constexpr (j < NPL) {
       unsigned char* P = s_patch + buf * PBUF;
-      const int pgcb = S == 0 ? pgcbA : pgcbB;
-      const bool pcok = S == 0 ? pcokA : pcokB;
-      uint4 v;
-      if constexpr (S == 0) v = pregA[j]; else v = pregB[j];
+      const int pgcb = SET_GET(S, pgcbA, pgcbB, pgcbC, pgcbD);
+      const bool pgn = SET_GET(S, pgnA, pgnB, pgnC, pgnD);
+      const bool pcok = SET_GET(S, pcokA, pcokB, pcokC, pcokD);
+      uint4 v = SET_GET(S, pregA[j], pregB[j], pregC[j], pregD[j]);
       if constexpr (GNP) {
-        if (pgcb >= 0)                     // wave-uniform: a property of the segment
+        if (pgn)                           // wave-uniform: a property of the segment (scalar branch)
           v = gn_transform16<T>(v, s_gn + pgcb, s_gn + CONV_GN_MAXC + pgcb, p.gn_silu != 0);
       }
       if (!(((pmask >> j) & 1u) && pcok)) v = uint4{0u, 0u, 0u, 0u};   // padding AFTER the activation
@@ -166,17 +196,14 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   // k-half kk reads (n-tile n0/16 + j, chunk 4 kk + fk, row frow) - the 64 lanes of a wave load
   // 1 KiB contiguous (with row-major [CoutPad][128 B] weights consecutive lanes would sit 128 B apart
   // and every lane would be its own memory transaction: measured 3.2 us per channel chunk).
-  // Two register sets (A: even chunks, B: odd chunks): a set is reloaded with the weights of chunk
-  // c+2 as soon as the MFMAs of chunk c have consumed it, so every load has a whole chunk of slack.
   // w?0 / w?1: the two k-halves of this wave's tap; w?s: this wave's k-half of the shared tap
   // (tap 8, or the only tap of a 1-tap segment).
-  uint4 wA0[NT], wA1[NT], wAs[NT], wB0[NT], wB1[NT], wBs[NT];
+  [[maybe_unused]] uint4 wA0[NT], wA1[NT], wAs[NT], wB0[NT], wB1[NT], wBs[NT], wC0[NT], wC1[NT], wCs[NT], wD0[NT], wD1[NT], wDs[NT];
   const int kkw = (wave >> 2) & 1;          // shared tap: this wave's k-half ...
   const int miw = wave & 3;                 // ... and m-tiles i with (i & 3) == miw
-  auto w_ptr = [&](int s, int c, int kbase_s, bool shared) __attribute__((always_inline)) {
-    const int nch = seg_nch(s);
-    const int tap = SEG_FIELD(p, s, taps) == 9 ? (shared ? 8 : wave) : 0;
-    const int kidx = kbase_s + tap * nch + c;
+  auto w_ptr = [&](bool shared) __attribute__((always_inline)) {          // the cursor chunk's fragments
+    const int tap = L_taps == 9 ? (shared ? 8 : wave) : 0;
+    const int kidx = L_kb + tap * L_nch + L_c;
     return reinterpret_cast<const T*>(p.w) + ((int64_t)kidx * p.CoutPad + n0) * KC +
            (((shared ? kkw * 4 : 0) + fk) * 16 + frow) * VW;
   };
@@ -203,27 +230,22 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   };
 
   // ---- main loop over (segment, channel chunk) ----------------------------------------------------------
-  // chunk cursors: cur (computing), n1 (its patch is being written), n2 (being loaded); a cursor past
-  // the end stays on the last chunk (loads are unconditional, their results are never consumed)
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  int cs = 0, cc = 0, kbase = 0;
-  auto advance = [&](int& s_, int& c_, int& kb_) __attribute__((always_inline)) {   // -> false at the end
-    const int nch = seg_nch(s_);
-    if (c_ + 1 < nch) { ++c_; return true; }
-    if (s_ + 1 < p.nseg) { kb_ += SEG_FIELD(p, s_, taps) * nch; ++s_; c_ = 0; return true; }
-    return false;
-  };
-  auto load_w = [&](auto SET, int s_, int c_, int kb_) __attribute__((always_inline)) {
+  using S2 = std::integral_constant<int, 2>;
+  using S3 = std::integral_constant<int, 3>;
+  auto load_w = [&](auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    const T* wp = w_ptr(s_, c_, kb_, false);
-    const T* wq = w_ptr(s_, c_, kb_, true);
+    const T* wp = w_ptr(false);
+    const T* wq = w_ptr(true);
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const uint4 v0 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
       const uint4 v1 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
       const uint4 vs = *reinterpret_cast<const uint4*>(wq + (int64_t)j * 16 * KC);
-      if constexpr (S == 0) { wA0[j] = v0; wA1[j] = v1; wAs[j] = vs; } else { wB0[j] = v0; wB1[j] = v1; wBs[j] = vs; }
+      SET_PUT(S, wA0[j], wB0[j], wC0[j], wD0[j], v0);
+      SET_PUT(S, wA1[j], wB1[j], wC1[j], wD1[j], v1);
+      SET_PUT(S, wAs[j], wBs[j], wCs[j], wDs[j], vs);
     }
   };
   // split over workgroups (p.ksplit > 1, grid.z): this workgroup owns chunks [zb, ze) of the conv and
@@ -236,17 +258,22 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   const int zraw = (int)blockIdx.z * zper;
   const int nmine = max(min(ntotal, zraw + zper) - zraw, 0);   // (a trailing workgroup may own nothing: it adds zeros)
   const int zb = min(zraw, ntotal - 1);
-  for (int i = 0; i < zb; ++i) (void)advance(cs, cc, kbase);
-  int s1 = cs, c1 = cc, kb1 = kbase;      // chunk 1 (or chunk 0 again when there is only one)
-  bool more = advance(s1, c1, kb1);
-  int s2 = s1, c2 = c1, kb2 = kb1;        // chunk 2
-  if (more) more = advance(s2, c2, kb2);
+  for (int i = 0; i < zb; ++i) advance();
+  // The cursor stops on this workgroup's last chunk: loads are unconditional (a load under a branch would make
+  // every later wait in the loop conservative), the surplus ones fetch that chunk again - cache hits whose
+  // results nobody consumes.
+  int lidx = 0;
+  auto next_load = [&]() __attribute__((always_inline)) {
+    if (lidx + 1 < nmine) { advance(); ++lidx; }
+  };
   STAMP_RT(60);
   STAMP(0);
-  load_patch(S0{}, cs, cc);
-  load_w(S0{}, cs, cc, kbase);
-  load_patch(S1{}, s1, c1);
-  load_w(S1{}, s1, c1, kb1);
+  load_patch(S0{}); load_w(S0{}); next_load();
+  load_patch(S1{}); load_w(S1{}); next_load();
+  if constexpr (D == 4) {
+    load_patch(S2{}); load_w(S2{}); next_load();
+    load_patch(S3{}); load_w(S3{}); next_load();
+  }
   STAMP(1);
   build_gn_table();
   __syncthreads();
@@ -257,85 +284,92 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   int nstamp = 4;
   (void)nstamp;
 
-  // one chunk: SET = its parity.  LDS buffer SET holds its patch, register set SET its weights.
+  // one chunk: SET = its register set (chunk index mod D); LDS buffer SET & 1 holds its patch.
+  // Every global load of the loop sits in straight-line code: a load inside one arm of an if / else makes the
+  // compiler wait for ALL outstanding loads (s_waitcnt vmcnt(0)) wherever the other arm reuses its destination
+  // registers.  Only LDS reads, MFMAs and the GroupNorm arithmetic are conditional.
   auto chunk = [&](auto SET) __attribute__((always_inline)) {
     constexpr int S = decltype(SET)::value;
-    using OTHER = std::integral_constant<int, 1 - S>;
-    const int ntaps = SEG_FIELD(p, cs, taps);
-    load_patch(SET, s2, c2);              // patch of chunk c+2 -> this parity's registers (free since last barrier)
-    const unsigned char* P = s_patch + S * PBUF;
-    // weights of chunk c+2 are requested fragment by fragment right behind the MFMAs that consumed the
-    // register (the 64 B/clk vector-memory path is as busy as the matrix pipe here: they must overlap)
-    const T* wp = w_ptr(s2, c2, kb2, false);
-    const T* wq = w_ptr(s2, c2, kb2, true);
-    if (ntaps == 9) {
-      {
-        uint4 af[MT < 2 ? 2 : MT];         // (not [1]: one-element arrays end up in scratch memory)
+    using NEXT = std::integral_constant<int, (S + 1) % D>;
+    constexpr int LB = S & 1;
+    const bool t9 = SET_GET(S, t9A, t9B, t9C, t9D);
+    // this set's next tenant: chunk c+D (the patch registers are free since the last barrier; the weight
+    // fragments are requested right behind the MFMAs that consumed the register)
+    const T* wp = w_ptr(false);
+    const T* wq = w_ptr(true);
+    load_patch(SET);
+    const unsigned char* P = s_patch + LB * PBUF;
+    if (t9) {
+      uint4 af[MT < 2 ? 2 : MT];         // (not [1]: one-element arrays end up in scratch memory)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 0);
+      for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 0);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int i = 0; i < MT; ++i) mma(S == 0 ? wA0[j] : wB0[j], af[i], acc[j][i]);
-          const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
-          if constexpr (S == 0) wA0[j] = v; else wB0[j] = v;
-        }
-      }
-      write_patch_item(OTHER{}, std::integral_constant<int, 0>{}, 1 - S);    // patch of chunk c+1, item 0
-      {
-        uint4 af[MT < 2 ? 2 : MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 1);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-#pragma unroll
-          for (int i = 0; i < MT; ++i) mma(S == 0 ? wA1[j] : wB1[j], af[i], acc[j][i]);
-          const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
-          if constexpr (S == 0) wA1[j] = v; else wB1[j] = v;
-        }
-      }
-    } else {
-      write_patch_item(OTHER{}, std::integral_constant<int, 0>{}, 1 - S);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {        // (own-tap registers are not used by 1-tap chunks; keep them loaded)
-        const uint4 v0 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
-        const uint4 v1 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
-        if constexpr (S == 0) { wA0[j] = v0; wA1[j] = v1; } else { wB0[j] = v0; wB1[j] = v1; }
-      }
+        for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA0[j], wB0[j], wC0[j], wD0[j]), af[i], acc[j][i]);
     }
-    write_patch_item(OTHER{}, std::integral_constant<int, 1>{}, 1 - S);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {          // (1-tap chunks do not use the own-tap registers; they stay loaded)
+      const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
+      SET_PUT(S, wA0[j], wB0[j], wC0[j], wD0[j], v);
+    }
+    write_patch_item(NEXT{}, std::integral_constant<int, 0>{}, 1 - LB);    // patch of chunk c+1, item 0
+    if (t9) {
+      uint4 af[MT < 2 ? 2 : MT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 1);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA1[j], wB1[j], wC1[j], wD1[j]), af[i], acc[j][i]);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
+      SET_PUT(S, wA1[j], wB1[j], wC1[j], wD1[j], v);
+    }
+    write_patch_item(NEXT{}, std::integral_constant<int, 1>{}, 1 - LB);
     {   // shared tap: tap 8 of a 9-tap chunk, or the only tap of a 1-tap chunk
-      const int srow0 = crow0 + (ntaps == 9 ? PCW + 1 : 0);
+      const int srow0 = crow0 + (t9 ? PCW + 1 : 0);
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         if ((i & 3) == miw) {
           const uint4 af = a_frag(P, srow0 + i * MROW, kkw);
 #pragma unroll
-          for (int j = 0; j < NT; ++j) mma(S == 0 ? wAs[j] : wBs[j], af, acc[j][i]);
+          for (int j = 0; j < NT; ++j) mma(SET_GET(S, wAs[j], wBs[j], wCs[j], wDs[j]), af, acc[j][i]);
         }
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         const uint4 v = *reinterpret_cast<const uint4*>(wq + (int64_t)j * 16 * KC);
-        if constexpr (S == 0) wAs[j] = v; else wBs[j] = v;
+        SET_PUT(S, wAs[j], wBs[j], wCs[j], wDs[j], v);
       }
     }
     STAMP(nstamp + 32);
-    write_patch_item(OTHER{}, std::integral_constant<int, 2>{}, 1 - S);
-    write_patch_item(OTHER{}, std::integral_constant<int, 3>{}, 1 - S);
+    write_patch_item(NEXT{}, std::integral_constant<int, 2>{}, 1 - LB);
+    write_patch_item(NEXT{}, std::integral_constant<int, 3>{}, 1 - LB);
+    next_load();
     __syncthreads();
     STAMP(nstamp);
     ++nstamp;
-    // cursors: cur <- n1 <- n2 <- n2 + 1
-    cs = s1; cc = c1; kbase = kb1;
-    s1 = s2; c1 = c2; kb1 = kb2;
-    if (more) more = advance(s2, c2, kb2);
   };
-  for (int c = 0; c < nmine; c += 2) {
-    chunk(S0{});
-    if (c + 1 < nmine) chunk(S1{});
+  // whole groups of D chunks run unconditionally (waits counted exactly across the loop), the last 1 .. D-1 behind
+  {
+    int c = 0;
+    for (; c + D <= nmine; c += D) {
+      chunk(S0{});
+      chunk(S1{});
+      if constexpr (D == 4) { chunk(S2{}); chunk(S3{}); }
+    }
+    const int rem = nmine - c;
+    if (rem > 0) chunk(S0{});
+    if constexpr (D == 4) {
+      if (rem > 1) chunk(S1{});
+      if (rem > 2) chunk(S2{});
+    }
   }
-  (void)cc; (void)kbase;
+#undef SET_PUT
+#undef SET_GET
 
   // ---- sum the 8 waves: 4..7 -> 0..3 through slabs, then slabs 0..3 are summed by output tile -------
   f32x4* red = reinterpret_cast<f32x4*>(smem);

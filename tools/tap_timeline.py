@@ -52,6 +52,6 @@ def run(B, H, W, cin, cout, gn):
         print(f"   {nm:24s} {(st[i] - t0) * ns_per_tick:9.0f} ns")
 
 
-for shape in [(1, 64, 64, 256, 256), (1, 64, 64, 512, 256), (1, 16, 16, 256, 256)]:
+for shape in [(1, 64, 64, 256, 256), (1, 32, 32, 256, 256), (1, 16, 16, 256, 256), (1, 4, 4, 256, 256)]:
     for gn in (False, True):
         run(*shape, gn)

@@ -577,7 +577,9 @@ extern "C" int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int firs
       // workgroup reads from L2 by itself, cost more than the tap-outer kernel's shared LDS tile
       static const char* tmax = getenv("FDBM_TAP_MAX_GRID");   // experiments
       if (grid(4) <= (tmax ? atoi(tmax) : 1024)) {
-        const int nt = (Cout >= 64 && grid(4) >= 192) ? 4 : (Cout >= 32 && grid(2) >= 192) ? 2 : 1;
+        static const char* fnt = getenv("FDBM_TAP_NT");         // experiments: force the n-tiles of the small grids
+        int nt = (Cout >= 64 && grid(4) >= 192) ? 4 : (Cout >= 32 && grid(2) >= 192) ? 2 : 1;
+        if (fnt && nt == 1 && Cout >= 64) nt = atoi(fnt);
         *kind = 2; *th = tw; *bm = 16; *bn = 16 * nt; *ksplit = 1;
       }
     }

@@ -175,19 +175,33 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
   const float g0 = p.gn_gamma[ce0], be0 = p.gn_beta[ce0], g1 = p.gn_gamma[ce1], be1 = p.gn_beta[ce1];
   double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
   if (g < G && part < nparts && p.gn_unit) {
-    // units of 4 channels, one buffer per segment: group g = units [g * upg, (g + 1) * upg)
+    // units of 4 channels, one buffer per segment: group g = units [g * upg, (g + 1) * upg).  The group's
+    // upg x (rows of its segment) partial sums are dealt out item by item over the parts, two loads in
+    // flight per thread (with 16 parts a thread usually owns one item: one memory round trip)
     const int upg = (C / G) >> 2;
-    for (int u = g * upg; u < (g + 1) * upg; ++u) {
+    auto item = [&](int t, double& s0, double& s1) __attribute__((always_inline)) {
+      // t -> (unit u = g * upg + t % upg, row t / upg); rows beyond the unit's segment add nothing
+      const int u = g * upg + t % upg, sp = t / upg;
       const int sg = (p.seg_gn[1] >= 0 && u >= p.gn_uoff[1]) ? ((p.seg_gn[2] >= 0 && u >= p.gn_uoff[2]) ? ((p.seg_gn[3] >= 0 && u >= p.gn_uoff[3]) ? 3 : 2) : 1) : 0;
       const double* base = sg == 0 ? p.gn_useg[0] : sg == 1 ? p.gn_useg[1] : sg == 2 ? p.gn_useg[2] : p.gn_useg[3];
       const int usp = sg == 0 ? p.gn_unsp[0] : sg == 1 ? p.gn_unsp[1] : sg == 2 ? p.gn_unsp[2] : p.gn_unsp[3];
       const int ucnt = sg == 0 ? p.gn_ucnt[0] : sg == 1 ? p.gn_ucnt[1] : sg == 2 ? p.gn_ucnt[2] : p.gn_ucnt[3];
       const int uoff = sg == 0 ? p.gn_uoff[0] : sg == 1 ? p.gn_uoff[1] : sg == 2 ? p.gn_uoff[2] : p.gn_uoff[3];
-      const double* sf = base + (((int64_t)(b0 + bl)) * usp * ucnt + (u - uoff)) * 2;
-      for (int sp = part; sp < usp; sp += nparts) {
-        const double* q = sf + (int64_t)sp * ucnt * 2;
-        a0 += q[0]; a1 += q[1];
-      }
+      const bool live = sp < usp;
+      const double* q = base + ((((int64_t)(b0 + bl)) * usp + (live ? sp : 0)) * ucnt + (u - uoff)) * 2;
+      const double v0 = q[0], v1 = q[1];
+      s0 = live ? v0 : 0.0; s1 = live ? v1 : 0.0;
+    };
+    int maxsp = p.gn_unsp[0];
+    if (p.seg_gn[1] >= 0) maxsp = max(maxsp, p.gn_unsp[1]);
+    if (p.seg_gn[2] >= 0) maxsp = max(maxsp, p.gn_unsp[2]);
+    if (p.seg_gn[3] >= 0) maxsp = max(maxsp, p.gn_unsp[3]);
+    const int T = upg * maxsp;
+    for (int t = part; t < T; t += 2 * nparts) {
+      double x0, x1, y0 = 0.0, y1 = 0.0;
+      item(t, x0, x1);
+      if (t + nparts < T) item(t + nparts, y0, y1);
+      a0 += x0; a1 += x1; c0 += y0; c1 += y1;
     }
   } else if (g < G && part < nparts) {
     if (p.gn_nsplit < 0) {

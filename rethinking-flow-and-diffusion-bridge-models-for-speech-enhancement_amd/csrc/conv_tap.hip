@@ -299,44 +299,98 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
     const T* wq = w_ptr(true);
     load_patch(SET);
     const unsigned char* P = s_patch + LB * PBUF;
-    // all fragment reads of the chunk first (one LDS round trip instead of three), then its MFMAs, then the
-    // reloads, then the next patch's items
-    const int srow0 = crow0 + (t9 ? PCW + 1 : 0);       // shared tap: tap 8 of a 9-tap chunk, or the only tap of a 1-tap chunk
-    const uint4 afs = a_frag(P, srow0 + (MT >= 4 ? miw : 0) * MROW, kkw);
-    if (t9) {
-      uint4 af0[MT < 2 ? 2 : MT], af1[MT < 2 ? 2 : MT];         // (not [1]: one-element arrays end up in scratch memory)
+    if constexpr (NT == 1) {
+      // all fragment reads of the chunk first (one LDS round trip instead of three), then its MFMAs, then the
+      // reloads, then the next patch's items
+      const int srow0 = crow0 + (t9 ? PCW + 1 : 0);       // shared tap: tap 8 of a 9-tap chunk, or the only tap of a 1-tap chunk
+      const uint4 afs = a_frag(P, srow0 + (MT >= 4 ? miw : 0) * MROW, kkw);
+      if (t9) {
+        uint4 af0[MT < 2 ? 2 : MT], af1[MT < 2 ? 2 : MT];         // (not [1]: one-element arrays end up in scratch memory)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) { af0[i] = a_frag(P, arow0 + i * MROW, 0); af1[i] = a_frag(P, arow0 + i * MROW, 1); }
+        for (int i = 0; i < MT; ++i) { af0[i] = a_frag(P, arow0 + i * MROW, 0); af1[i] = a_frag(P, arow0 + i * MROW, 1); }
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA0[j], wB0[j], wC0[j], wD0[j]), af0[i], acc[j][i]);
+          for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA0[j], wB0[j], wC0[j], wD0[j]), af0[i], acc[j][i]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA1[j], wB1[j], wC1[j], wD1[j]), af1[i], acc[j][i]);
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      if ((i & 3) == miw) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) mma(SET_GET(S, wAs[j], wBs[j], wCs[j], wDs[j]), afs, acc[j][i]);
+          for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA1[j], wB1[j], wC1[j], wD1[j]), af1[i], acc[j][i]);
       }
-    }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {          // (1-tap chunks do not use the own-tap registers; they stay loaded)
-      const uint4 v0 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
-      const uint4 v1 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
-      const uint4 vs = *reinterpret_cast<const uint4*>(wq + (int64_t)j * 16 * KC);
-      SET_PUT(S, wA0[j], wB0[j], wC0[j], wD0[j], v0);
-      SET_PUT(S, wA1[j], wB1[j], wC1[j], wD1[j], v1);
-      SET_PUT(S, wAs[j], wBs[j], wCs[j], wDs[j], vs);
+      for (int i = 0; i < MT; ++i) {
+        if ((i & 3) == miw) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma(SET_GET(S, wAs[j], wBs[j], wCs[j], wDs[j]), afs, acc[j][i]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {          // (1-tap chunks do not use the own-tap registers; they stay loaded)
+        const uint4 v0 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
+        const uint4 vs = *reinterpret_cast<const uint4*>(wq + (int64_t)j * 16 * KC);
+        SET_PUT(S, wA0[j], wB0[j], wC0[j], wD0[j], v0);
+        SET_PUT(S, wA1[j], wB1[j], wC1[j], wD1[j], v1);
+        SET_PUT(S, wAs[j], wBs[j], wCs[j], wDs[j], vs);
+      }
+      STAMP(nstamp + 32);
+      write_patch_item(NEXT{}, std::integral_constant<int, 0>{}, 1 - LB);    // patch of chunk c+1
+      write_patch_item(NEXT{}, std::integral_constant<int, 1>{}, 1 - LB);
+      write_patch_item(NEXT{}, std::integral_constant<int, 2>{}, 1 - LB);
+      write_patch_item(NEXT{}, std::integral_constant<int, 3>{}, 1 - LB);
+    } else {
+      // wide tiles: the next patch's items between the MFMA groups, whose length covers the VALU work of the
+      // partner wave on the SIMD
+      if (t9) {
+        uint4 af[MT < 2 ? 2 : MT];         // (not [1]: one-element arrays end up in scratch memory)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA0[j], wB0[j], wC0[j], wD0[j]), af[i], acc[j][i]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {          // (1-tap chunks do not use the own-tap registers; they stay loaded)
+        const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC);
+        SET_PUT(S, wA0[j], wB0[j], wC0[j], wD0[j], v);
+      }
+      write_patch_item(NEXT{}, std::integral_constant<int, 0>{}, 1 - LB);    // patch of chunk c+1, item 0
+      if (t9) {
+        uint4 af[MT < 2 ? 2 : MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA1[j], wB1[j], wC1[j], wD1[j]), af[i], acc[j][i]);
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const uint4 v = *reinterpret_cast<const uint4*>(wp + (int64_t)j * 16 * KC + 64 * VW);
+        SET_PUT(S, wA1[j], wB1[j], wC1[j], wD1[j], v);
+      }
+      write_patch_item(NEXT{}, std::integral_constant<int, 1>{}, 1 - LB);
+      {   // shared tap: tap 8 of a 9-tap chunk, or the only tap of a 1-tap chunk
+        const int srow0 = crow0 + (t9 ? PCW + 1 : 0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          if ((i & 3) == miw) {
+            const uint4 af = a_frag(P, srow0 + i * MROW, kkw);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) mma(SET_GET(S, wAs[j], wBs[j], wCs[j], wDs[j]), af, acc[j][i]);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const uint4 v = *reinterpret_cast<const uint4*>(wq + (int64_t)j * 16 * KC);
+          SET_PUT(S, wAs[j], wBs[j], wCs[j], wDs[j], v);
+        }
+      }
+      STAMP(nstamp + 32);
+      write_patch_item(NEXT{}, std::integral_constant<int, 2>{}, 1 - LB);
+      write_patch_item(NEXT{}, std::integral_constant<int, 3>{}, 1 - LB);
     }
-    STAMP(nstamp + 32);
-    write_patch_item(NEXT{}, std::integral_constant<int, 0>{}, 1 - LB);    // patch of chunk c+1
-    write_patch_item(NEXT{}, std::integral_constant<int, 1>{}, 1 - LB);
-    write_patch_item(NEXT{}, std::integral_constant<int, 2>{}, 1 - LB);
-    write_patch_item(NEXT{}, std::integral_constant<int, 3>{}, 1 - LB);
     next_load();
     __syncthreads();
     STAMP(nstamp);

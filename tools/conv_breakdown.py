@@ -35,5 +35,7 @@ for i, (opc, ia, fa, _lane) in enumerate(prog.ops):
         bn = 64 if ca.Cout <= 64 else 128
         blocks = ((ca.B * ca.H * ca.W + 127) // 128) * ((ca.Cout + bn - 1) // bn)
         print(f"{n:12s} {ca.H:4d} {ca.W:4d} {ca.Cout:5d} {K:6d} {nk:4d} {blocks:7d} {best[i]*1e3:8.1f} {fl/best[i]/1e9:8.1f}")
+    elif best[i] * 1e3 > 7.0:
+        print(f"{n:12s} ints {list(ia[:16])} {best[i]*1e3:8.1f}")
 print("totals (us):", {k: round(v * 1e3, 1) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}, "sum", round(sum(best) * 1e3, 1), "n_ops", prog.n_ops)
 print("pool bytes", prog.pool.total_bytes() / 1e6, "MB")

@@ -560,13 +560,10 @@ extern "C" int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int firs
   // tap-outer kernel's smaller tiles fill the chip better
   static const char* pmin = getenv("FDBM_PATCH_MIN_TILES");  // experiments
   const int64_t min_tiles = pmin ? atoi(pmin) : 128;
-  if ((conv_policy() & 1) && first_taps == 9 && H % 8 == 0 && W % 16 == 0 && *ksplit == 1 && tiles16 >= min_tiles) {
-    *kind = 1;
-    *th = (H % 16 == 0 && tiles16 >= 256) ? 16 : 8;
-    return 0;
-  }
+  const bool patch_ok = (conv_policy() & 1) && first_taps == 9 && H % 8 == 0 && W % 16 == 0 && *ksplit == 1 && tiles16 >= min_tiles;
+  // wave-per-tap kernel: its tile shape and grid for this layer
+  int tw = 0, tr = 0, tap_nt = 0;
   if ((first_taps == 9 || first_taps == 1) && (conv_policy() & 2)) {   // (1x1: the shared-tap path alone)
-    int tw = 0, tr = 0;
     if (W % 16 == 0 && H % 4 == 0) { tw = 16; tr = 4; }
     else if (W % 8 == 0 && H % 8 == 0) { tw = 8; tr = 8; }
     else if (W % 4 == 0 && H % 4 == 0) { tw = 4; tr = 4; }
@@ -578,12 +575,19 @@ extern "C" int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int firs
       static const char* tmax = getenv("FDBM_TAP_MAX_GRID");   // experiments
       if (grid(4) <= (tmax ? atoi(tmax) : 1024)) {
         static const char* fnt = getenv("FDBM_TAP_NT");         // experiments: force the n-tiles of the small grids
-        int nt = (Cout >= 64 && grid(4) >= 192) ? 4 : (Cout >= 32 && grid(2) >= 192) ? 2 : 1;
-        if (fnt && nt == 1 && Cout >= 64) nt = atoi(fnt);
-        *kind = 2; *th = tw; *bm = 16; *bn = 16 * nt; *ksplit = 1;
+        tap_nt = (Cout >= 64 && grid(4) >= 192) ? 4 : (Cout >= 32 && grid(2) >= 192) ? 2 : 1;
+        if (fnt && tap_nt == 1 && Cout >= 64) tap_nt = atoi(fnt);
       }
     }
   }
+  // a conv with <= 16 output channels (the 4-channel heads) would spend 128 channels' worth of MFMAs in the
+  // halo-patch kernel: where the wave-per-tap grid is allowed, its 16-channel tile does the same work
+  if (patch_ok && !(Cout <= 16 && tap_nt)) {
+    *kind = 1;
+    *th = (H % 16 == 0 && tiles16 >= 256) ? 16 : 8;
+    return 0;
+  }
+  if (tap_nt) { *kind = 2; *th = tw; *bm = 16; *bn = 16 * tap_nt; *ksplit = 1; }
   return 0;
 }
 

@@ -144,7 +144,7 @@ __global__ void __launch_bounds__(256) resample2x_tile_kernel(
     T* __restrict__ out_plain, T* __restrict__ out_act, const T* __restrict__ in,
     const float* __restrict__ stats, int nsplit, double inv_count, float eps,
     const float* __restrict__ gamma, const float* __restrict__ beta,
-    int H, int W, int C, int G, int upg, int tiles_x) {
+    int H, int W, int C, int G, int upg, int tiles_x, int ntiles) {
   constexpr int VW = DT<T>::vecw;
   constexpr int CCH = 16, CV = CCH / VW;          // channels per workgroup, 16-byte vectors of them
   constexpr int PS = CCH + 4;                       // LDS pixel stride in floats (bank spread)
@@ -157,11 +157,14 @@ __global__ void __launch_bounds__(256) resample2x_tile_kernel(
   float* s_act = s_raw + IH * IW * PS;
   const int b = blockIdx.z;
   const int c0 = blockIdx.y * CCH;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
-  // input coordinates of the staged tile's first pixel
-  const int iy0 = UP ? ty * 8 - 1 : ty * 16 - 1, ix0 = UP ? tx * 8 - 1 : tx * 16 - 1;
   gn_scale_shift(s_ss, s_red, stats, nsplit, inv_count, eps, b, C, G, gamma, beta, upg);
   const T* img = in + (int64_t)b * H * W * C;
+  // a workgroup walks tiles blockIdx.x, + gridDim.x, ...: the scale/shift table (statistics rows -> fp64 reduce
+  // -> per-channel entries, three barriers of pure latency) is built once per workgroup, not once per tile
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  const int ty = tile / tiles_x, tx = tile % tiles_x;
+  // input coordinates of the staged tile's first pixel
+  const int iy0 = UP ? ty * 8 - 1 : ty * 16 - 1, ix0 = UP ? tx * 8 - 1 : tx * 16 - 1;
   for (int i = threadIdx.x; i < IH * IW * CV; i += 256) {
     const int v = i % CV, px = i / CV;
     const int iy = iy0 + px / IW, ix = ix0 + px % IW;
@@ -224,6 +227,8 @@ __global__ void __launch_bounds__(256) resample2x_tile_kernel(
     const int64_t oidx = (((int64_t)b * OH + oy) * OW + ox) * C + c0 + v * VW;
     if (PLAIN) Vec16<T>::store(out_plain + oidx, accp);
     Vec16<T>::store(out_act + oidx, acca);
+  }
+  __syncthreads();          // the staged tile is free for the next one
   }
 }
 
@@ -308,7 +313,11 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
     const int tiles_x = up ? W / 8 : W / 16, tiles_y = up ? H / 8 : H / 16;
     const int npx = up ? 100 : 324;
     const size_t smem = (2 * (size_t)C + 2 * (size_t)npx * 20) * sizeof(float);
-    dim3 grid(tiles_x * tiles_y, C / 16, B);
+    // >= 2 workgroups per CU in flight, then tiles are walked inside the workgroup
+    const int ntiles = tiles_x * tiles_y;
+    int gx = ntiles;
+    while (gx > 64 && (int64_t)(gx / 2) * (C / 16) * B >= 512) gx = (gx + 1) / 2;
+    dim3 grid(gx, C / 16, B);
 #define RT(TT, U, P)                                                                                     \
   do {                                                                                                   \
     static bool attr = false;                                                                            \
@@ -318,7 +327,7 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
       attr = true;                                                                                       \
     }                                                                                                    \
     resample2x_tile_kernel<TT, U, P><<<grid, 256, smem, st>>>((TT*)out_plain, (TT*)out_act, (const TT*)in, stats, nsplit, \
-                                                              inv_count, eps, gamma, beta, H, W, C, G, stat_units, tiles_x); \
+                                                              inv_count, eps, gamma, beta, H, W, C, G, stat_units, tiles_x, ntiles); \
   } while (0)
 #define RT_DISPATCH(TT)                                                              \
   do {                                                                               \

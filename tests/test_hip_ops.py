@@ -340,6 +340,7 @@ CONV_CASES = [
     ("tap_32_b2", 2, 32, 32, [128], 64, 9, dict(res=True, tbias=True)),
     ("tap_8x8_c96", 3, 8, 8, [96, 32], 96, 9, dict(shortcut=[96])),
     ("tap_4x8", 2, 4, 8, [64], 32, 9, {}),
+    ("head_full_map", 1, 256, 256, [128], 4, 9, dict(head=True)),               # 4 output channels: 16-channel wave-per-tap tile, 1024 workgroups
     ("head_up_patch", 1, 128, 128, [128], 4, 9, dict(head_up=True)),            # residual upsampled in the epilogue
     ("head_up_tap", 2, 16, 16, [64], 4, 9, dict(head_up=True)),
     ("head_up_tapouter", 1, 12, 20, [64], 4, 9, dict(head_up=True)),
@@ -421,6 +422,33 @@ def test_conv_full_size_linearity(dtype):
         ref = (q(x)[0, :, yy - 1:yy + 2, xx - 1:xx + 2][None] * q(w)).sum((1, 2, 3))
         tol = 2e-5 if dtype == torch.float32 else 2e-2
         assert (o1[0, :, yy, xx] - ref).abs().max() < tol
+
+
+@pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("HW", [4, 8, 16], ids=["4x4", "8x8", "16x16"])
+@pytest.mark.parametrize("cin,cin1", [(64, 0), (128, 0), (192, 64), (320, 0), (384, 192), (448, 64), (576, 0)],
+                         ids=["1", "2", "3+1", "5", "6+3", "7+1", "9"])
+def test_conv_tap_chunk_remainders(cin, cin1, HW, dtype, splitk):
+    """The wave-per-tap kernel keeps 4 register sets of 64-channel chunks in flight on its one-n-tile tiles (groups
+    of 4 chunks unrolled, then a 1..3 chunk tail; a load cursor that stops on the workgroup's last chunk): every
+    remainder of the chunk count, with and without a 1-tap shortcut segment behind the 9-tap one, with the channel
+    chunks split over workgroups (zeroed scratch) and not."""
+    B, cout = 2, 32
+    x = rnd(B, cin, HW, HW, seed=cin + HW)
+    w = rnd(cout, cin, 3, 3, seed=5) / math.sqrt(cin * 9)
+    q = lambda t: t.to(dtype).float()
+    ref = F.conv2d(q(x), q(w), None, padding=1)
+    segs, weights = [(x, 9)], [w]
+    if cin1:
+        x1 = rnd(B, cin1, HW, HW, seed=cin1 + 7)
+        w1 = rnd(cout, cin1, 1, 1, seed=6) / math.sqrt(cin1)
+        ref = ref + F.conv2d(q(x1), q(w1))
+        segs.append((x1, 1)); weights.append(w1)
+    assert hip.conv_plan_ex(B, HW, HW, cout, 9 * ((cin + 63) // 64), 9)["kind"] == 2
+    out, _, _ = run_conv(segs, weights, None, dtype, splitk=splitk)
+    err = (out - ref).abs().max().item()
+    assert err < (2e-5 if dtype == torch.float32 else 2e-2), err
 
 
 FUSED_CASES = [

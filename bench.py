@@ -16,7 +16,7 @@ bf16 storage + fp32 accumulate.  --batch 64 gives configs[2].
 Rank 0 prints ONE JSON line.  `roofline` prices conv_patch_kernel (MFMA-bound, 65 % of the
 algorithmic flops) from HIP-event timings of its launches in one eager forward, lists every
 convolution kernel family the same way (`families`) and carries the HBM bytes per launch
-measured offline with rocprofv3 PMC passes (profiles/r01/e_pmc_traffic_b1_bf16.json);
+measured offline with rocprofv3 PMC passes (profiles/r01/f_pmc_traffic_b1_bf16.json);
 `cpu_baseline` times the CPU oracle (a port, oracle/) on a bounded sample on the host cores.
 FDBM_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks.
 """
@@ -262,7 +262,9 @@ def main():
     f_dom = sum(flops[i] for i in sel)
     achieved = f_dom / t_dom / 1e12
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "e_pmc_traffic_b1_bf16.json")
+    pmc = os.path.join(ROOT, "profiles", "r01", "f_pmc_traffic_b1_bf16.json")
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r01", "e_pmc_traffic_b1_bf16.json")
     if args.batch == 1 and args.dtype == "bf16" and os.path.exists(pmc):
         try:        # measured offline with rocprofv3 --pmc (tools/pmc_workload.py), bytes per launch
             traffic = json.load(open(pmc))["conv_patch_kernel"]["hbm_bytes_per_launch_corrected"]

@@ -19,6 +19,10 @@
 // 1.4-2.3 x the tile instead of 9 x) and no slab / second launch is needed.
 // 1-tap segments (the res-block's 1x1 shortcut in the same accumulator) follow the 9-tap ones
 // and are handled like the shared tap (with the centre shift).
+// Pipeline: D register sets (patch items + weight fragments of chunks c .. c+D-1; D = 4 on the one-n-tile tiles
+// of the small maps, 2 on the wide tiles) behind ONE load cursor whose segment fields live in scalars; LDS patch
+// double-buffered (chunk c+1 is transformed and written while chunk c computes); every global load in
+// straight-line code so that hipcc counts its waits (vmcnt(13..15) in the loop, not vmcnt(0)).
 // Tiles: TW = 16 | 8 | 4 pixels wide (16/TW image rows per 16-pixel MFMA m-tile), so that 8x8
 // and 4x4 maps are one tile.  Roofline: latency-bound by design (these layers hold < 1 us of
 // MFMA work per CU); it is selected only when the grid is small (fdbm_conv_plan_ex).

@@ -236,13 +236,19 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
     double var = t1 * p.gn_inv_count - mean * mean;
     if (var < 0.0) var = 0.0;
     s_mr[2 * slot] = (float)mean;
-    s_mr[2 * slot + 1] = (float)(1.0 / sqrt(var + (double)p.gn_eps));
+    // 1 / sqrt in fp64 as v_rsq_f64 + one Newton step (error ~1e-15, far below the float it is rounded to)
+    // instead of the sqrt + division sequences (~40 instructions on the launch's critical path)
+    const double x = var + (double)p.gn_eps;
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    s_mr[2 * slot + 1] = (float)r;
   }
   __syncthreads();
   const int cpg = C / G;
+  const float inv_cpg = 1.0f / (float)cpg, inv_C = 1.0f / (float)C;     // (exact quotients for these small integers)
   for (int i = tid, it = 0; i < nb * C; i += NTHR, ++it) {
-    const int ib = i / C, c = i - ib * C;
-    const int gg = c / cpg;
+    const int ib = nb == 1 ? 0 : (int)(((float)i + 0.5f) * inv_C), c = i - ib * C;
+    const int gg = (int)(((float)c + 0.5f) * inv_cpg);
     const float ga = it == 0 ? g0 : it == 1 ? g1 : p.gn_gamma[c];
     const float be = it == 0 ? be0 : it == 1 ? be1 : p.gn_beta[c];
     const float sc = s_mr[2 * (ib * 32 + gg) + 1] * ga;

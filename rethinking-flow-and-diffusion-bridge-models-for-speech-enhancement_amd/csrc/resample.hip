@@ -9,6 +9,7 @@
 //    feeding both outputs of a res-block (resample(x) and resample(act(gn(x)))).
 //    HBM-bound: down reads 1x writes 1/4x; up reads 1x writes 4x.
 #include "common.h"
+#include <cstdlib>
 
 __global__ void __launch_bounds__(256) upfirdn2d_kernel(
     float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ kern, int major,
@@ -309,7 +310,13 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
   FDBM_CHECK(up || (H % 2 == 0 && W % 2 == 0), "fdbm_resample2x: downsampling needs even H, W (got %d x %d)", H, W);
   hipStream_t st = (hipStream_t)stream;
   // fused GroupNorm+SiLU on maps that tile: the LDS-staged kernel (one activation per input element)
-  if (out_act && C % 16 == 0 && (up ? (H % 8 == 0 && W % 8 == 0) : (H % 16 == 0 && W % 16 == 0))) {
+  // ... up to 64 x 64 pixels.  Above that the plain kernel - one output vector per thread, the activation recomputed
+  // per tap - is faster at every batch size once it runs on enough workgroups (measured: 48.6 -> 49.0 x real time
+  // at batch 1, 129.8 -> 134.2 at batch 64): the tiled kernel's 16-channel slices read 32 bytes of every 256-byte
+  // pixel per workgroup and its 18 x 18 staging pass keeps 60 % of the threads busy.
+  static const char* tmax = getenv("FDBM_RESAMPLE_TILE_MAXHW");       // experiments
+  const int64_t tile_max_hw = tmax ? atoll(tmax) : 4096;
+  if (out_act && C % 16 == 0 && (int64_t)H * W <= tile_max_hw && (up ? (H % 8 == 0 && W % 8 == 0) : (H % 16 == 0 && W % 16 == 0))) {
     const int tiles_x = up ? W / 8 : W / 16, tiles_y = up ? H / 8 : H / 16;
     const int npx = up ? 100 : 324;
     const size_t smem = (2 * (size_t)C + 2 * (size_t)npx * 20) * sizeof(float);

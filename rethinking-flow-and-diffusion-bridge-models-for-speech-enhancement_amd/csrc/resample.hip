@@ -355,7 +355,9 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
   const int64_t total = (int64_t)OH * OW * (C / vw);
   // one output vector per thread up to 2048 workgroups (4 per thread left a 1 MB pyramid level on 16 CUs: 13 us of latency)
   int chunks = (int)((total + 255) / 256);
-  if (chunks > 2048) chunks = 2048;
+  static const char* cmax = getenv("FDBM_RESAMPLE_MAX_CHUNKS");      // experiments
+  const int chunk_cap = cmax ? atoi(cmax) : 2048;
+  if (chunks > chunk_cap) chunks = chunk_cap;
   if (chunks < 1) chunks = 1;
   dim3 grid(chunks, B);
   const size_t smem = out_act ? 2 * (size_t)C * sizeof(float) : 0;

@@ -67,7 +67,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
     const int iy = y0 + pr - 1, ix = x0 + pc - 1;
     const bool ok = (q < PROWS * 8) && iy >= 0 && iy < H && ix >= 0 && ix < W;
     ppix[j] = min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1);
-    plds[j] = (q < PROWS * 8) ? prow * 128 + ((pch ^ ((prow >> 1) & 7)) << 4) : -1;
+    plds[j] = (q < PROWS * 8) ? prow * 128 + ((pch ^ ((pc >> 1) & 7)) << 4) : -1;     // swizzle key from the patch COLUMN (see a_base)
     pmask |= ok ? (1u << j) : 0u;
   }
   const int pchunk = tid & 7;          // NTHR is a multiple of 8: the 16-byte chunk is fixed per thread
@@ -161,6 +161,16 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // Fragment addresses as (per-lane base) + (wave-uniform offset) + (immediate): the XOR swizzle key of a patch row
+  // is taken from its COLUMN pc = frow + dx ((pc >> 1) & 7 - within one ds_read_b128 the 16 lanes read 16 consecutive
+  // columns of one patch row, exactly the rows the key has to spread), so it depends on the lane and on dx only; the
+  // key of a weight row (wn * 64 + j * 16 + frow) is (frow >> 1) & 7 whatever j and wn.  rocprofv3 counted 6.5 VALU
+  // instructions per MFMA in this kernel with the addresses recomputed per fragment - more issue cycles than the MFMAs.
+#define A_BASE(DX, KK) ((wm * 4 * PC + frow + (DX)) * 128 + ((((KK) * 4 + fk) ^ (((frow + (DX)) >> 1) & 7)) << 4))
+  const int ab00 = A_BASE(0, 0), ab01 = A_BASE(0, 1), ab10 = A_BASE(1, 0), ab11 = A_BASE(1, 1), ab20 = A_BASE(2, 0), ab21 = A_BASE(2, 1);
+#undef A_BASE
+  const int wb0 = (wn * 64 + frow) * 128 + (((0 * 4 + fk) ^ ((frow >> 1) & 7)) << 4);
+  const int wb1 = (wn * 64 + frow) * 128 + (((1 * 4 + fk) ^ ((frow >> 1) & 7)) << 4);
   // one half (kk = 0 | 1: 16 of the 32 k-values of a 128-byte row) of a k-step's MFMAs
   auto compute = [&](int pbuf, int wbuf, int dy, int dx, int kk) __attribute__((always_inline)) {
     const unsigned char* P = s_patch + pbuf * PBUF;
@@ -173,18 +183,14 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
         for (int i = 0; i < MT; ++i) part[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     {
-      const int cidx = kk * 4 + fk;
       uint4 wf[NT], af[MT];
+      const unsigned char* wsrc = Wt + (kk == 0 ? wb0 : wb1);
+      const unsigned char* asrc = P + dy * (PC * 128) +
+                                  (kk == 0 ? (dx == 0 ? ab00 : dx == 1 ? ab10 : ab20) : (dx == 0 ? ab01 : dx == 1 ? ab11 : ab21));
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int row = wn * 64 + j * 16 + frow;
-        wf[j] = *reinterpret_cast<const uint4*>(Wt + row * 128 + ((cidx ^ ((row >> 1) & 7)) << 4));
-      }
+      for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const uint4*>(wsrc + j * (16 * 128));
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        const int row = (wm * 4 + i + dy) * PC + frow + dx;
-        af[i] = *reinterpret_cast<const uint4*>(P + row * 128 + ((cidx ^ ((row >> 1) & 7)) << 4));
-      }
+      for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(asrc + i * (PC * 128));
       if constexpr (!F32) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)

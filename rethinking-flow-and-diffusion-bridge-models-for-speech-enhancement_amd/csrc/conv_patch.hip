@@ -192,10 +192,12 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(asrc + i * (PC * 128));
       if constexpr (!F32) {
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int i = 0; i < MT; ++i) Mfma<bf16_t>::run(wf[j], af[i], acc[j][i]);
+        __builtin_amdgcn_s_setprio(0);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q)

@@ -493,14 +493,16 @@ extern "C" int fdbm_conv_kc(int dtype) { return dtype == FDBM_BF16 ? 64 : 32; }
 // k-groups inside the workgroup (see conv_igemm_kernel): 4 for the 64 x 64 tile when the layer has
 // too few tiles to give every CU two workgroups and enough k-steps to share out (opt-in).
 // Kernel-selection policy: bit 0 = halo-patch kernel allowed, bit 1 = wave-per-tap kernel allowed,
-// bit 2 = k-groups in the tap-outer kernel.  Default 3, or from the environment (experiments):
-// FDBM_CONV_PATCH=0, FDBM_CONV_TAP=0 clear a bit, FDBM_CONV_KG=4 sets bit 2.
+// bit 2 = k-groups in the tap-outer kernel, bit 3 = producer/consumer ring kernel (conv_ring.hip) in place of the
+// halo-patch kernel where it applies.  Default 11, or from the environment (experiments):
+// FDBM_CONV_PATCH=0, FDBM_CONV_TAP=0, FDBM_CONV_RING=0 clear a bit, FDBM_CONV_KG=4 sets bit 2.
 static int g_policy = -1;
 static int conv_policy() {
   if (g_policy < 0) {
-    int m = 3;
+    int m = 11;
     const char* e;
     if ((e = getenv("FDBM_CONV_PATCH")) && e[0] == '0') m &= ~1;
+    if ((e = getenv("FDBM_CONV_RING")) && e[0] == '0') m &= ~8;
     if ((e = getenv("FDBM_CONV_TAP")) && e[0] == '0') m &= ~2;
     if ((e = getenv("FDBM_CONV_KG")) && e[0] == '4') m |= 4;
     g_policy = m;
@@ -509,7 +511,7 @@ static int conv_policy() {
 }
 extern "C" int fdbm_conv_policy(int mask) {
   const int old = conv_policy();
-  if (mask >= 0) g_policy = mask & 7;
+  if (mask >= 0) g_policy = mask & 15;
   return old;
 }
 
@@ -544,6 +546,8 @@ extern "C" int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int
 
 int fdbm_launch_conv_patch(const ConvParams& p, int dt_in, int dt_out, int th, hipStream_t st);   // conv_patch.hip
 int fdbm_launch_conv_tap(const ConvParams& p, int dt_in, int dt_out, int tw, int nt, hipStream_t st);   // conv_tap.hip
+int fdbm_launch_conv_ring(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                  // conv_ring.hip
+bool fdbm_conv_ring_ok(const ConvParams& p);
 
 // Which kernel runs a conv of this shape: kind 1 = halo-patch 3x3 kernel (conv_patch.hip, tile
 // th x 16 pixels x 128 channels), kind 2 = wave-per-tap 3x3 kernel for small grids (conv_tap.hip,
@@ -690,6 +694,13 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     p.stat_out = a->stat_out; p.stat_G = a->stat_G; p.stat_nsplit = a->stat_nsplit;
   }
   hipStream_t st = (hipStream_t)stream;
+  if (kind == 1 && (conv_policy() & 8) && a->dt_in == FDBM_BF16 && fdbm_conv_ring_ok(p)) {
+    // producer / consumer ring kernel: one 512-thread workgroup per CU on a 16 x 16 pixel x 128 channel tile; wants
+    // (nearly) a tile per CU, below that the halo-patch kernel's 8-row tiles fill the chip better
+    static const char* rmin = getenv("FDBM_RING_MIN_TILES");   // experiments
+    const int64_t tiles = (int64_t)a->B * (a->H / 16) * (a->W / 16) * ((a->Cout + 127) / 128);
+    if (tiles >= (rmin ? atoi(rmin) : 200)) return fdbm_launch_conv_ring(p, a->dt_in, a->dt_out, st);
+  }
   if (kind == 1) {
     // 8-row tiles let two workgroups share a CU (their load / epilogue phases then overlap the other's
     // MFMAs) as long as the GroupNorm table stays within 2 KiB: measured +2...11 % over 16-row tiles

@@ -91,22 +91,24 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 // final value of 4 consecutive output channels of pixel m: bias, time-embedding bias, residual,
 // scale, Combine; stores and returns the stored (rounded) values in v.
+// (loads of absent operands read this instead of sitting behind a branch, see conv_epilogue4)
+static __device__ const float g_conv_zero[4] = {0.f, 0.f, 0.f, 0.f};
+
 template <typename TO>
 __device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int64_t m, int64_t b, int n, float* v) {
   const int Cout = p.Cout;
-  if (p.bias) {
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + n);
-    v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
-  }
-  if (p.tbias) {
-    const f32x4 tv = *reinterpret_cast<const f32x4*>(p.tbias + b * p.tbias_stride + n);
-    v[0] += tv[0]; v[1] += tv[1]; v[2] += tv[2]; v[3] += tv[3];
-  }
-  if (p.res) {
-    float r[4];
-    OutVec<TO>::load(reinterpret_cast<const TO*>(p.res) + m * Cout + n, r);
-    v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
-  }
+  // The three common operands are fetched UNCONDITIONALLY (an absent one from a zero vector): a load behind a branch is
+  // waited for on its own, and bias -> time bias -> residual became three serialised memory round trips per element.
+  const float* bp = p.bias ? p.bias + n : g_conv_zero;
+  const float* tp = p.tbias ? p.tbias + b * p.tbias_stride + n : g_conv_zero;
+  const TO* rp = p.res ? reinterpret_cast<const TO*>(p.res) + m * Cout + n : reinterpret_cast<const TO*>(g_conv_zero);
+  const f32x4 bv = *reinterpret_cast<const f32x4*>(bp);
+  const f32x4 tv = *reinterpret_cast<const f32x4*>(tp);
+  float r[4];
+  OutVec<TO>::load(rp, r);
+  v[0] += bv[0]; v[1] += bv[1]; v[2] += bv[2]; v[3] += bv[3];
+  v[0] += tv[0]; v[1] += tv[1]; v[2] += tv[2]; v[3] += tv[3];
+  v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3];
   if (p.res_lo) {       // upsample_2d of the low-resolution residual, tap order of resample2x_kernel
     const int HW = p.H * p.W;
     const int rr = (int)(m - b * HW);

@@ -3,7 +3,9 @@
 N=30 steps on 16 kHz / 4 s clips).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL)
+  (N > 1: one rank per GPU over RCCL.  Under torch.distributed.run - WORLD_SIZE set - this process is one rank; started
+   bare with --gpus N > 1 it launches the N ranks itself, before touching any GPU, and relays rank 0's JSON line)
+  python bench.py --gpus 8 --clips 2000 --batch 64      BASELINE configs[3]: a list of clips sharded over the ranks
 
 A "step" is one pass of the hot path over one batch of synthetic clips already resident
 in HBM:  normalise -> STFT + compression + time padding -> N=30 ODE-EI sampler (30 NCSN++
@@ -13,10 +15,10 @@ Workload at every N (weak scaling): BASELINE.json configs[1] per rank - one synt
 4 s clip, ncsnpp_v2 (65.6 M parameters, deterministic synthetic weights), bridge sb/bb,
 bf16 storage + fp32 accumulate.  --batch 64 gives configs[2].
 
-Rank 0 prints ONE JSON line.  `roofline` prices conv_patch_kernel (MFMA-bound, 65 % of the
-algorithmic flops) from HIP-event timings of its launches in one eager forward, lists every
-convolution kernel family the same way (`families`) and carries the HBM bytes per launch
-measured offline with rocprofv3 PMC passes (profiles/r01/f_pmc_traffic_b1_bf16.json);
+Rank 0 prints ONE JSON line.  `roofline` prices the convolution kernel that carries most of the
+algorithmic flops (conv_ring_kernel, MFMA-bound, 65 % of them) from HIP-event timings of its launches
+in one eager forward, lists every convolution kernel family the same way (`families`) and carries
+the HBM bytes per launch measured offline with rocprofv3 PMC passes (profiles/r0*/..pmc_traffic..json);
 `cpu_baseline` times the CPU oracle (a port, oracle/) on a bounded sample on the host cores.
 FDBM_BENCH_BACKEND=gloo rehearses the N > 1 control flow on a box with fewer GPUs than ranks.
 """
@@ -74,12 +76,10 @@ class HotPath:
 
     def enhance(self, wave):
         """infer_folder.py:102-121 per batch.  Returns (enhanced waveform, enhanced spectrogram)."""
-        nf = wave.abs().amax(dim=1, keepdim=True)
-        Y = self.fe.spec_forward_padded(wave / nf, self.pad_mode)
+        nf = self.fe.norm_factor(wave)                                    # max |y| per clip (fdbm_wave_norm_factor)
+        Y = self.fe.spec_forward_padded(wave, self.pad_mode, norm=nf)     # y / nf fused into the STFT launch
         X = self.bridge.sampler(self.net, Y, generator=self.gen)
-        x_hat = self.fe.to_audio(X[:, 0], wave.shape[-1]) * nf
-        peak = x_hat.abs().amax(dim=1, keepdim=True)
-        x_hat = torch.where(peak > 1.0, x_hat / peak * 0.95, x_hat)
+        x_hat = self.fe.to_audio(X[:, 0], wave.shape[-1], norm=nf, clip=0.95)   # * nf and the 0.95 clip rule fused
         return x_hat, X
 
 
@@ -93,7 +93,7 @@ def time_conv_launches(net, B, F, T, reps=3):
     best = [float("inf")] * len(conv_ids)
     fwd_ms = float("inf")
     for _ in range(reps):
-        evs = []
+        evs, launched = [], []
         e0 = torch.cuda.Event(enable_timing=True); e0.record()
         lo = 0
         for i in conv_ids:
@@ -101,6 +101,7 @@ def time_conv_launches(net, B, F, T, reps=3):
                 prog.run_range(lo, i)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record(); prog.run_range(i, i + 1); b.record()
+            launched.append(hip.lib().fdbm_conv_last_kind())
             evs.append((a, b))
             lo = i + 1
         prog.run_range(lo, prog.n_ops)
@@ -111,12 +112,10 @@ def time_conv_launches(net, B, F, T, reps=3):
         fwd_ms = min(fwd_ms, e0.elapsed_time(e1))
     # algorithmic flops of each conv launch (all segments), whole batch; which kernel runs it
     flops, kinds = [], []
-    kc = hip.conv_kc(prog.dtc)
     for ca in prog.keep_conv:
         k = sum(ca.seg[s].cin * ca.seg[s].taps for s in range(ca.nseg))
         flops.append(2.0 * ca.B * ca.H * ca.W * ca.Cout * k)
-        nk = sum(ca.seg[s].taps * ((ca.seg[s].cin + kc - 1) // kc) for s in range(ca.nseg))
-        kinds.append(hip.conv_plan_ex(ca.B, ca.H, ca.W, ca.Cout, nk, ca.seg[0].taps)["kind"])
+    kinds = launched            # kernel family of each launch as the library reports it (fdbm_conv_last_kind)
     return best, flops, kinds, fwd_ms, prog
 
 
@@ -152,12 +151,36 @@ def cpu_baseline(n_forwards, n_steps):
                        f"{cores} threads, {t_fwd:.2f} s each) + full front-end/back-end; sampler extrapolated x{n_steps}/{n_forwards}")
 
 
+def launch_ranks(n, argv):
+    """--gpus n > 1 without a launcher: start the n ranks (one per GPU, RCCL) as children of THIS process, which has
+    not touched a GPU (never re-exec a process that has), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+    if proc.returncode != 0 or line is None:
+        sys.stderr.write(proc.stdout)
+        sys.exit(proc.returncode or 1)
+    print(line)
+    sys.exit(0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1, help="clips per rank per step (1 = configs[1], 64 = configs[2])")
+    ap.add_argument("--clips", type=int, default=0,
+                    help="configs[3]: a list of this many synthetic clips, strided over the ranks, enhanced in batches of "
+                         "--batch; a step = the whole list once (strong scaling)")
     ap.add_argument("--N", type=int, default=30, help="sampler steps")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--backbone", default="ncsnpp_v2")
@@ -166,14 +189,20 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32-parity-mode and batch-64 side measurements")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args.gpus, sys.argv[1:])
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # FDBM_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
     # (ranks share devices, the gather goes through host memory); the real runs use RCCL
     backend = os.environ.get("FDBM_BENCH_BACKEND", "nccl")
     if backend == "gloo":
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    comm_world = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -181,29 +210,49 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend)
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+        comm_world = dist.get_world_size()
+        assert comm_world == args.gpus, (comm_world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
     dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
 
+    from fdbm_amd import dist as fdist
     hp = HotPath(dev, dtype, args.N, args.batch, backbone=args.backbone)
-    wave = synth_clips(args.batch, 1000 + rank, dev)            # resident in HBM before timing
+    if args.clips:
+        # configs[3]: the list is sharded by index (rank r takes clips r, r + W, ...: fdbm_amd.dist.shard_indices), every
+        # rank walks its shard in batches of --batch (a ragged last batch is padded with its first clip and trimmed)
+        mine = fdist.shard_indices(args.clips, rank, world)
+        waves = [synth_clips(1, 5000 + i, dev) for i in mine]              # resident in HBM before timing
+        n_batches = (len(mine) + args.batch - 1) // args.batch
+        batches = []
+        for bi in range(n_batches):
+            part = waves[bi * args.batch:(bi + 1) * args.batch]
+            real = len(part)
+            part = part + [part[0]] * (args.batch - real)
+            batches.append((torch.cat(part, 0), real))
+        # every rank runs the same number of gather rounds (a rank whose shard is a batch shorter sends an empty one)
+        rounds = (len(fdist.shard_indices(args.clips, 0, world)) + args.batch - 1) // args.batch
+    else:
+        batches = [(synth_clips(args.batch, 1000 + rank, dev), args.batch)]   # resident in HBM before timing
+        rounds = 1
+    wave = batches[0][0]
 
     def step():
-        x_hat, X = hp.enhance(wave)
-        if os.environ.get("FDBM_BENCH_DEBUG"):
-            torch.cuda.synchronize()
-            print(f"[dbg] rank {rank}: wave finite {bool(torch.isfinite(wave).all())} max {float(wave.abs().max()):.3g}; "
-                  f"X finite {bool(torch.isfinite(torch.view_as_real(X)).all())}; x_hat finite {bool(torch.isfinite(x_hat).all())}",
-                  file=sys.stderr, flush=True)
-        if world > 1:
-            import torch.distributed as dist
-            xr = torch.view_as_real(X.contiguous())
-            if backend != "nccl":
-                xr = xr.cpu()
-            gathered = [torch.empty_like(xr) for _ in range(world)] if rank == 0 else None
-            dist.gather(xr, gathered, dst=0)                     # enhanced spectrograms only, over RCCL/xGMI
+        x_hat = None
+        for r in range(rounds):
+            if r < len(batches):
+                w, real = batches[r]
+                x_hat, X = hp.enhance(w)
+                X = X[:real]
+            else:
+                X = X[:0]
+            if os.environ.get("FDBM_BENCH_DEBUG"):
+                torch.cuda.synchronize()
+                print(f"[dbg] rank {rank}: X finite {bool(torch.isfinite(torch.view_as_real(X)).all())}; "
+                      f"x_hat finite {bool(torch.isfinite(x_hat).all())}", file=sys.stderr, flush=True)
+            if world > 1:
+                # enhanced spectrograms only, to rank 0, over RCCL / xGMI (gloo rehearsal: through host memory)
+                fdist.gather_spectrograms(X if backend == "nccl" else X.cpu(), dst=0)
         return x_hat
 
     def barrier():
@@ -226,7 +275,8 @@ def main():
         elapsed = float(tt.item())
     assert torch.isfinite(out).all(), f"rank {rank}: {int((~torch.isfinite(out)).sum())} non-finite samples of {out.numel()}"
 
-    audio_s = world * args.steps * args.batch * CLIP_SECONDS
+    n_clips_step = args.clips if args.clips else world * args.batch
+    audio_s = args.steps * n_clips_step * CLIP_SECONDS
     rtf = audio_s / elapsed
     if rank != 0:
         if world > 1:
@@ -241,13 +291,16 @@ def main():
         "value": rtf, "unit": "x real-time (audio-s / wall-s)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "strong" if args.clips else "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": f"BASELINE configs[{1 if args.batch == 1 else 2}]: {args.batch} synthetic 4 s 16 kHz clip(s) per rank per step, "
+        "config": {"workload": (f"BASELINE configs[3]: {args.clips} synthetic 4 s 16 kHz clips sharded by index over the ranks, batches of {args.batch}, "
+                                if args.clips else
+                                f"BASELINE configs[{1 if args.batch == 1 else 2}]: {args.batch} synthetic 4 s 16 kHz clip(s) per rank per step, ") +
                                f"{args.backbone} (deterministic synthetic weights), bridge sb/bb, ode_ei N={args.N}, "
                                "STFT 512/256 sqrt-Hann -> [257 x 256] complex spectrogram",
-                   "batch_per_rank": args.batch, "sampler_steps": args.N, "parallelism": f"dp{world} (utterance sharding, gather of spectrograms)"},
-        "whole_step_tflops": world * args.batch * args.N * flops_fwd / (elapsed / args.steps) / 1e12,
+                   "batch_per_rank": args.batch, "sampler_steps": args.N, "rccl_world_size": comm_world,
+                   "parallelism": f"dp{world} (utterance sharding, gather of spectrograms)"},
+        "whole_step_tflops": n_clips_step * args.N * flops_fwd / (elapsed / args.steps) / 1e12,
     }
 
     # ---- roofline of the dominant kernel ---------------------------------------------------
@@ -257,21 +310,20 @@ def main():
     # latency-bound small-map layers.
     times, flops, kinds, fwd_ms, prog = time_conv_launches(hp.net, args.batch, F, T)
     peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
-    sel = [i for i, k in enumerate(kinds) if k == 1] or list(range(len(times)))
+    dom = 3 if any(k == 3 for k in kinds) else 1
+    sel = [i for i, k in enumerate(kinds) if k == dom] or list(range(len(times)))
     t_dom = sum(times[i] for i in sel) * 1e-3
     f_dom = sum(flops[i] for i in sel)
     achieved = f_dom / t_dom / 1e12
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r01", "f_pmc_traffic_b1_bf16.json")
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r01", "e_pmc_traffic_b1_bf16.json")
-    if args.batch == 1 and args.dtype == "bf16" and os.path.exists(pmc):
+    fam_name = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel", 3: "conv_ring_kernel"}
+    pmc = os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_b{args.batch}_bf16.json")
+    if args.dtype == "bf16" and os.path.exists(pmc):
         try:        # measured offline with rocprofv3 --pmc (tools/pmc_workload.py), bytes per launch
-            traffic = json.load(open(pmc))["conv_patch_kernel"]["hbm_bytes_per_launch_corrected"]
+            traffic = json.load(open(pmc))[fam_name[dom]]["hbm_bytes_per_launch_corrected"]
         except Exception:
             traffic = None
     t_conv = sum(times) * 1e-3
-    fam_name = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel"}
     families = {}
     for kind, name in fam_name.items():
         ids = [i for i, k in enumerate(kinds) if k == kind]
@@ -281,7 +333,7 @@ def main():
                               "achieved": ff / tt / 1e12, "frac": ff / tt / 1e12 / peak,
                               "share_of_forward_flops": ff / sum(flops), "share_of_conv_time": tt / t_conv}
     result["roofline"] = {
-        "bound": "mfma", "kernel": "conv_patch_kernel" if any(k == 1 for k in kinds) else "conv_igemm_kernel",
+        "bound": "mfma", "kernel": fam_name[dom] if any(k == dom for k in kinds) else "conv_igemm_kernel",
         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
         "launches_per_forward": len(sel), "avg_launch_us": 1e6 * t_dom / len(sel),
         "algorithmic_gflop_per_launch_avg": f_dom / len(sel) / 1e9,
@@ -303,7 +355,7 @@ def main():
             t1 = time.perf_counter(); hp32.enhance(w1); hp32.enhance(w1); torch.cuda.synchronize()
             extras["fp32_parity_mode_rtf_b1"] = 2 * CLIP_SECONDS / (time.perf_counter() - t1)
             del hp32
-            if args.batch == 1:
+            if args.batch == 1 and not args.clips:
                 hp64 = HotPath(dev, dtype, args.N, 64, backbone=args.backbone)
                 w64 = synth_clips(64, 77, dev)
                 hp64.enhance(w64); torch.cuda.synchronize()

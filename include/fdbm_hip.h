@@ -242,9 +242,14 @@ int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int* ksplit);
 int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int first_taps, int* kind, int* th,
                       int* bm, int* bn, int* ksplit);
 /* kernel-selection policy used by fdbm_conv_plan_ex / fdbm_conv_igemm: bit 0 allows kind 1, bit 1
- * allows kind 2, bit 2 turns on k-groups inside the kind-0 kernel; mask < 0 only queries.
- * Returns the previous mask (default 3).  Results are the same convolution under every policy. */
+ * allows kind 2, bit 2 turns on k-groups inside the kind-0 kernel, bit 3 lets the producer / consumer
+ * ring kernel (csrc/conv_ring.hip: bf16 input, 16 x 16 pixel tiles, >= 200 tiles) take the place of
+ * kind 1; mask < 0 only queries.  Returns the previous mask (default 11).  Results are the same
+ * convolution under every policy. */
 int fdbm_conv_policy(int mask);
+/* kernel family of the most recent fdbm_conv_igemm launch of this process: 0 tap-outer implicit GEMM,
+ * 1 halo-patch, 2 wave-per-tap, 3 ring; -1 before the first call (for measurement harnesses) */
+int fdbm_conv_last_kind(void);
 
 /* Combine('sum'): out = conv1x1(4->C)(pyr) + h (layerspp.py:52-57; ncsnpp_v2.py:302-305).
  * pyr f32 [M][4], w f32 [C][4], bias f32 [C], h/out dtype [M][C]; out may alias h. */
@@ -269,6 +274,21 @@ int fdbm_istft(float* wave /*[B][L]*/, const void* spec /*c64 [B][bins][Tpad]*/,
                const float* window, float* frames_ws /*[B][frames][n_fft]*/, int B, int L,
                int n_fft, int hop, int frames, int Tpad, int transform, float factor,
                float exponent, void* stream);
+
+/* Waveform normalisation either side of the path (infer_folder.py:102-107,118-121; infer_single.py:79-84,97-99;
+ * model.py:391-397,403), fused into the front-end:
+ *   fdbm_wave_norm_factor  nf[b] = max |y_b| (mode 0, normalize == "noisy") or torch.std(y_b) (mode 1, unbiased)
+ *   fdbm_stft_norm         fdbm_stft of y / nf (the division where the frame is windowed: same two roundings)
+ *   fdbm_istft_renorm      fdbm_istft, then x_hat * nf and, if max |x_hat| > 1, x_hat / max |x_hat| * clip
+ *                          (clip 0.95: infer_folder.py:121, 0.5: infer_single.py:99, 0: no clip rule);
+ *                          peak_ws: B x 4 bytes of scratch (holds max |x_hat * nf| per clip afterwards, as a float) */
+int fdbm_wave_norm_factor(float* nf /*[B]*/, const float* wave /*[B][L]*/, int B, int L, int mode, void* stream);
+int fdbm_stft_norm(void* spec, const float* wave, const float* window, const float* norm /*[B]*/, int B, int L,
+                   int n_fft, int hop, int frames, int Tpad, int pad_mode, int transform, float factor,
+                   float exponent, void* stream);
+int fdbm_istft_renorm(float* wave, const void* spec, const float* window, float* frames_ws, const float* norm /*[B]*/,
+                      void* peak_ws /*[B] x 4 bytes*/, float clip, int B, int L, int n_fft, int hop, int frames,
+                      int Tpad, int transform, float factor, float exponent, void* stream);
 
 /* Stand-alone spec_fwd (inverse=0) / spec_back (inverse=1) on complex64 data
  * (fdbm/data_module.py:173-199) and pad_spec (fdbm/util/other.py:76-90; mode 0 zero_pad,

@@ -101,3 +101,20 @@ def pad_mode_for(backbone_name):
     if backbone_name.startswith("ncsnpp"):
         return "zero_pad"
     return None
+
+
+def norm_factor(y, normalize="noisy"):
+    """infer_folder.py:102-105 / infer_single.py:79-83: max |y| ('noisy') or y.std() ('std') over the whole file."""
+    if normalize == "noisy":
+        return y.abs().max()
+    if normalize == "std":
+        return y.std()
+    raise ValueError(normalize)
+
+
+def renormalize(x_hat, nf, clip=0.95):
+    """infer_folder.py:118-121 (clip 0.95) / infer_single.py:97-99 (clip 0.5)."""
+    x_hat = x_hat * nf
+    if x_hat.abs().max() > 1.0:
+        x_hat = x_hat / x_hat.abs().max() * clip
+    return x_hat

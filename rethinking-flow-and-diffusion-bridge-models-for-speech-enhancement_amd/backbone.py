@@ -156,8 +156,11 @@ class HipNCSNpp:
         self.dense_w = torch.cat(dense_w, 0).contiguous()
         self.dense_b = torch.cat(dense_b, 0).contiguous()
         self.dense_rows = rows
+        # everything derived from the old tensors goes: programs / graphs hold their addresses, and the
+        # fragment-major copies are keyed by them (the allocator hands the freed addresses straight back)
         self._programs.clear()
         self._graphs.clear()
+        self._frag = {}
         return self
 
     def _concat_split(self, mod):
@@ -174,20 +177,30 @@ class HipNCSNpp:
         """Fragment-major copy of a packed conv weight (for the wave-per-tap kernel), made on first
         use and shared by every program of this network."""
         from .program import frag_major
-        if not hasattr(self, "_frag"):
-            self._frag = {}
         key = wpack.data_ptr()
-        if key not in self._frag:
-            self._frag[key] = frag_major(wpack)
-        return self._frag[key]
+        hit = self._frag.get(key)
+        if hit is None or hit[0] is not wpack:        # (the packed tensor is kept with its copy: an address alone can be reused)
+            hit = self._frag[key] = (wpack, frag_major(wpack))
+        return hit[1]
 
     # ---- programs ------------------------------------------------------------------------
+    MAX_PROGRAMS = 4      # shapes kept at once: a Program owns a full activation pool (linear in B), a graph per sampler
+
     def program(self, B, F, T):
+        """Recorded forward for this shape; least-recently-used shapes beyond MAX_PROGRAMS are dropped together with
+        their sampler graphs (a folder of mixed-length files would otherwise grow device memory without bound)."""
         key = (B, F, T)
-        if key not in self._programs:
+        prog = self._programs.pop(key, None)
+        if prog is None:
             with torch.cuda.device(self.device):
-                self._programs[key] = Program(self, B, F, T)
-        return self._programs[key]
+                prog = Program(self, B, F, T)
+            while len(self._programs) >= self.MAX_PROGRAMS:
+                old = next(iter(self._programs))
+                dead = self._programs.pop(old)
+                for gk in [k for k, v in self._graphs.items() if getattr(v, "prog", None) is dead]:
+                    del self._graphs[gk]
+        self._programs[key] = prog           # most recent last
+        return prog
 
     def forward(self, x, y, t):
         if not (x.is_cuda and y.is_cuda):

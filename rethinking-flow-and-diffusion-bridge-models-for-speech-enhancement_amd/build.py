@@ -16,17 +16,35 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "*.cpp")))
 
 
+STAMP = os.path.join(CSRC, ".build_stamp")
+
+
+def source_hash():
+    """sha256 over every source, header and the flags: what the built library is a function of."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    deps = sources() + sorted(glob.glob(os.path.join(CSRC, "*.h"))) + \
+        sorted(glob.glob(os.path.join(os.path.dirname(CSRC), "..", "include", "*.h")))
+    for d in deps:
+        h.update(os.path.basename(d).encode())
+        h.update(open(d, "rb").read())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB):
+    """The library is current iff it exists and was built from exactly these sources (hash stamp, not mtimes:
+    a shipped .so that merely LOOKS newer than the sources must not pass for a build)."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
-        glob.glob(os.path.join(os.path.dirname(CSRC), "..", "include", "*.h"))
-    return any(os.path.getmtime(d) > t for d in deps)
+    return open(STAMP).read().strip() != source_hash()
 
 
 def build(force=False, verbose=True):
+    """-> path of the library.  force (or FDBM_FORCE_BUILD=1): compile even when the stamp matches."""
+    force = force or os.environ.get("FDBM_FORCE_BUILD", "") not in ("", "0")
     if not force and not is_stale():
+        if verbose:
+            print(f"reused {LIB} (source hash {source_hash()[:12]} matches its build stamp)", flush=True)
         return LIB
     objs = []
     procs = []
@@ -53,6 +71,10 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    with open(STAMP, "w") as f:
+        f.write(source_hash() + "\n")
+    if verbose:
+        print(f"compiled {len(objs)} translation units -> {LIB} (source hash {source_hash()[:12]})", flush=True)
     return LIB
 
 

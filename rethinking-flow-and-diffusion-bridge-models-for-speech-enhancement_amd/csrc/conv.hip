@@ -497,6 +497,7 @@ extern "C" int fdbm_conv_kc(int dtype) { return dtype == FDBM_BF16 ? 64 : 32; }
 // halo-patch kernel where it applies.  Default 11, or from the environment (experiments):
 // FDBM_CONV_PATCH=0, FDBM_CONV_TAP=0, FDBM_CONV_RING=0 clear a bit, FDBM_CONV_KG=4 sets bit 2.
 static int g_policy = -1;
+static int g_last_kind = -1;      // kernel family of the most recent fdbm_conv_igemm launch (see fdbm_conv_last_kind)
 static int conv_policy() {
   if (g_policy < 0) {
     int m = 11;
@@ -509,6 +510,10 @@ static int conv_policy() {
   }
   return g_policy;
 }
+// 0 = tap-outer implicit GEMM, 1 = halo-patch, 2 = wave-per-tap, 3 = producer/consumer ring; -1 before the first call.
+// For measurement harnesses (bench.py prices each kernel family against its roofline).
+extern "C" int fdbm_conv_last_kind(void) { return g_last_kind; }
+
 extern "C" int fdbm_conv_policy(int mask) {
   const int old = conv_policy();
   if (mask >= 0) g_policy = mask & 15;
@@ -699,8 +704,9 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     // (nearly) a tile per CU, below that the halo-patch kernel's 8-row tiles fill the chip better
     static const char* rmin = getenv("FDBM_RING_MIN_TILES");   // experiments
     const int64_t tiles = (int64_t)a->B * (a->H / 16) * (a->W / 16) * ((a->Cout + 127) / 128);
-    if (tiles >= (rmin ? atoi(rmin) : 200)) return fdbm_launch_conv_ring(p, a->dt_in, a->dt_out, st);
+    if (tiles >= (rmin ? atoi(rmin) : 200)) { g_last_kind = 3; return fdbm_launch_conv_ring(p, a->dt_in, a->dt_out, st); }
   }
+  g_last_kind = kind;
   if (kind == 1) {
     // 8-row tiles let two workgroups share a CU (their load / epilogue phases then overlap the other's
     // MFMAs) as long as the GroupNorm table stays within 2 KiB: measured +2...11 % over 16-row tiles

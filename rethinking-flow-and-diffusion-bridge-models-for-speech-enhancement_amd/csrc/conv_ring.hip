@@ -8,26 +8,21 @@
 //              registers).  Their loop holds nothing but ds_read_b128 and v_mfma: the fragments of the next half
 //              k-step are read while the 32 MFMAs of the current one issue, so the matrix pipe of a SIMD is fed
 //              by ONE wave without gaps.
-//   waves 4-7  PRODUCERS, one per SIMD: stream the 16 KiB weight tile of every k-step into a 3-slot ring by LDS-DMA
-//              (global_load_lds_dwordx4, XOR swizzle applied on the SOURCE address) two k-steps ahead, and stage the
-//              next chunk's halo patch into the other patch buffer - by LDS-DMA too where the segment is read raw,
-//              through registers where a GroupNorm scale/shift + SiLU is applied on the way (VALU work that runs
-//              beside the consumer's MFMAs on the same SIMD: the two pipes are separate).
+//   waves 4-7  PRODUCERS, one per SIMD: stream the 16 KiB weight tile of every k-step into a 3-slot LDS ring (requested
+//              into registers 3 k-steps before it is written) and stage the next chunk's halo patch into the other
+//              patch buffer, GroupNorm scale/shift + SiLU applied on the way (VALU work that runs beside the
+//              consumer's MFMAs on the same SIMD: the two pipes are separate).
 // One raw s_barrier per k-step ("tick", in the MIDDLE of the consumers' step) is the only synchronisation:
-//   tick(s): producers have waited (counted vmcnt) for the weights of step s+1 and, at a chunk's last step, for the
-//            next patch; consumers have completed (lgkmcnt(0)) every LDS read they issued before it.
+//   tick(s): producers have written (lgkmcnt(0)) the weights of step s+1 and, at a chunk's last step, the next
+//            patch; consumers have completed every LDS read of the chunk at its last step.
 //   after tick(s) consumers read the first half of step s+1, producers overwrite ring slot (s+2) % 3 = (s-1) % 3
 //   and, at a chunk boundary, the patch buffer of the chunk that has just ended.
 // Roofline: MFMA-bound; 2*M*Cout*K flop per launch, K = 9*Cin (+ Cin of 1-tap shortcut segments).
 // Segment order expected by this kernel: 9-tap segments first, then 1-tap ones; GroupNorm only on 9-tap segments
 // (fdbm_conv_igemm falls back to conv_patch.hip otherwise).
+#include <stdlib.h>
+
 #include "conv_common.h"
-
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
-
-// zero page: source of the padding lanes of a patch LDS-DMA (pixels outside the image, channels beyond the segment)
-__device__ __attribute__((aligned(256))) unsigned char g_ring_zero[256];
 
 namespace ring {
 constexpr int PC = 18;                 // patch columns (16 + halo)
@@ -40,7 +35,6 @@ constexpr int GOFF = WOFF + NSLOT * WB;
 constexpr int NIT = 11;                // patch items (16 bytes) per producer thread: 324 rows x 8 / 256 threads
 }  // namespace ring
 
-#define RING_WAIT_VM(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
 
 // Diagnostic build only (-DFDBM_STAMPS, tools/ring_timeline.py): workgroup (0,0) writes shader-clock stamps of its
 // phases into the workspace (consumer wave 0: slots 0.., producer wave 4: slots 32..).  The product library has none.
@@ -55,9 +49,11 @@ constexpr int NIT = 11;                // patch items (16 bytes) per producer th
     if (p.partial && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == (T0))                    \
       reinterpret_cast<unsigned long long*>(p.partial)[i] = __builtin_amdgcn_s_memrealtime();      \
   } while (0)
+#define RDBG(bit) ((p.ksplit >> (bit)) & 1)      // experiments: p.ksplit carries FDBM_RING_DBG (1: no MFMA, 2: no transform, 4: no setprio)
 #else
 #define RSTAMP(i, T0)
 #define RSTAMP_RT(i, T0)
+#define RDBG(bit) 0
 #endif
 
 template <typename T, typename TO, bool GNP>
@@ -101,16 +97,16 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
   auto seg_nch = [&](int s) __attribute__((always_inline)) { return s == 0 ? sg_n0 : s == 1 ? sg_n1 : s == 2 ? sg_n2 : sg_n3; };
   auto seg_taps = [&](int s) __attribute__((always_inline)) { return s == 0 ? sg_t0 : s == 1 ? sg_t1 : s == 2 ? sg_t2 : sg_t3; };
 
-  // ---- patch 0 through registers by ALL 512 threads (segment 0 normalised): item j = patch row (tid / 8 + 64 j),
-  // 16-byte chunk tid & 7.  The loads are requested here, ahead of the GroupNorm table they need, and transformed
-  // behind it - with 8 waves this part of the launch's critical path takes half the time.
+  // ---- patch 0 through registers by ALL 512 threads: item j = patch row (tid / 8 + 64 j), 16-byte chunk tid & 7.
+  // The loads are requested here, ahead of the GroupNorm table they may need, and transformed behind it - with 8
+  // waves this part of the launch's critical path takes half the time.
   constexpr int NI0 = 6;
   uint4 p0reg[NI0];
   int p0lds[NI0];
   unsigned p0ok = 0;
   const bool reg0 = GNP && p.seg_gn[0] >= 0;
   const bool p0cok = (tid & 7) * VW < min(KC, (int)p.seg[0].cin);
-  if (reg0) {
+  {
     const T* src = reinterpret_cast<const T*>(p.seg[0].src) + img * p.seg[0].C + p.seg[0].coff + (p0cok ? (tid & 7) : 0) * VW;
 #pragma unroll
     for (int j = 0; j < NI0; ++j) {
@@ -121,39 +117,38 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       const bool ok = row < PROWS && iy >= 0 && iy < H && ix >= 0 && ix < W;
       p0ok |= (ok && p0cok) ? (1u << j) : 0u;
       p0lds[j] = row < PROWS ? row * 128 + (((tid & 7) ^ ((pc >> 1) & 7)) << 4) : -1;
-      // (plain loads, counted by the compiler: across the table build below it may spill or move these registers,
-      // which it must not do to the destination of a load it cannot see)
       p0reg[j] = *reinterpret_cast<const uint4*>(src + (int64_t)(ok ? iy * W + ix : 0) * p.seg[0].C);
     }
   }
   auto p0_store = [&]() __attribute__((always_inline)) {
+    float sc[8], sh[8];
     if constexpr (GNP) {
       if (reg0) {
         const int gcb = p.seg_gn[0] + (p0cok ? (tid & 7) : 0) * VW;
-        float sc[8], sh[8];
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(s_gn + gcb), a1 = *reinterpret_cast<const f32x4*>(s_gn + gcb + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_gn + gnpad + gcb), b1 = *reinterpret_cast<const f32x4*>(s_gn + gnpad + gcb + 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { sc[q] = a0[q]; sc[4 + q] = a1[q]; sh[q] = b0[q]; sh[4 + q] = b1[q]; }
-#pragma unroll
-        for (int j = 0; j < NI0; ++j) {
-          uint4 v = gn_transform16<T>(p0reg[j], sc, sh, p.gn_silu != 0);
-          if (!((p0ok >> j) & 1u)) v = uint4{0u, 0u, 0u, 0u};          // padding AFTER the activation
-          if (p0lds[j] >= 0) *reinterpret_cast<uint4*>(smem + p0lds[j]) = v;
-        }
       }
+    }
+#pragma unroll
+    for (int j = 0; j < NI0; ++j) {
+      uint4 v = p0reg[j];
+      if constexpr (GNP) { if (reg0) v = gn_transform16<T>(v, sc, sh, p.gn_silu != 0); }
+      if (!((p0ok >> j) & 1u)) v = uint4{0u, 0u, 0u, 0u};          // padding AFTER the activation
+      if (p0lds[j] >= 0) *reinterpret_cast<uint4*>(smem + p0lds[j]) = v;
     }
   };
 
   if (wave >= 4) {
     // =========================================== PRODUCERS ===========================================
+    // Everything is staged through registers with ordinary (compiler-counted) loads.  An LDS-DMA version of this
+    // role was measured first: one global_load_lds piece cost its wave ~230 cycles of issue beside the consumers' LDS
+    // reads, 4 pieces per wave and k-step took the producers' whole interval (tools/ring_timeline.py).
     RSTAMP(32, 256);
-    const int pw = wave - 4;
     const int ptid = tid - 256;
     const int pchunk = ptid & 7;
-    // item j of this thread = patch row (ptid / 8 + 32 j), 16-byte position pchunk of that row's 128 bytes.
-    //   through registers: load source chunk pchunk, store at LDS position pchunk ^ key(row)
-    //   by LDS-DMA (lane-linear destination): load source chunk pchunk ^ key(row) into position pchunk
+    // item j of this thread = patch row (ptid / 8 + 32 j), source chunk pchunk, LDS position pchunk ^ key(row)
     int ppix[NIT];          // pixel offset inside the image, -1: padding
     int plds[NIT];          // row * 128 + ((pchunk ^ key) << 4)
 #pragma unroll
@@ -166,38 +161,61 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       ppix[j] = ok ? iy * W + ix : -1;
       plds[j] = row * 128 + ((pchunk ^ ((pc >> 1) & 7)) << 4);
     }
-    // weight DMA: piece q = pw + 4 i (i = 0..3) of the 16 KiB tile = rows 8q .. 8q+7; lane -> row 8q + lane/8,
-    // LDS position lane & 7, source chunk (lane & 7) ^ ((row >> 1) & 7) - the same for every piece of this wave
-    const int wlane_off = (lane >> 3) * 128 + (((lane & 7) ^ ((4 * pw + (lane >> 4)) & 7)) << 4);
 
-    auto issue_w = [&](int kidx, int slot) __attribute__((always_inline)) {
-      const unsigned char* g = reinterpret_cast<const unsigned char*>(p.w) + ((int64_t)kidx * p.CoutPad + n0) * 128 + wlane_off;
-      unsigned char* l = smem + WOFF + slot * WB;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int q = pw + 4 * i;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)(g + q * 1024), (lds_ptr_t)(l + q * 1024), 16, 0, 0);
-      }
-    };
-
-    // weight cursor: the k-step whose tile is issued next
-    int w_seg = 0, w_c = 0, w_tap = 0, w_kbase = 0, w_step = 0, w_slot = 0;
-    auto next_w = [&]() __attribute__((always_inline)) {
-      if (w_step < nsteps) {
-        const int nch = seg_nch(w_seg), ntaps = seg_taps(w_seg);
-        issue_w(w_kbase + w_tap * nch + w_c, w_slot);
-        w_slot = w_slot == NSLOT - 1 ? 0 : w_slot + 1;
+    // ---- weights: the 16 KiB tile of k-step k lives in register set k % 3 (4 x 16 bytes per thread: rows ptid/8 + 32 i,
+    // chunk pchunk) and goes to ring slot k % 3; requested 3 intervals before it is written
+    const int wg_off = (ptid >> 3) * 128 + pchunk * 16;
+    const int wl_off = WOFF + (ptid >> 3) * 128 + ((pchunk ^ ((ptid >> 4) & 7)) << 4);
+    const unsigned char* wbase = reinterpret_cast<const unsigned char*>(p.w) + (int64_t)n0 * 128 + wg_off;
+    const int64_t wstep = (int64_t)p.CoutPad * 128;
+    // (twelve named registers: as arrays handed to lambdas these sets were placed in scratch memory by hipcc)
+    uint4 wa0, wa1, wa2, wa3, wb0_, wb1_, wb2_, wb3_, wc0, wc1, wc2, wc3;
+    int w_seg = 0, w_c = 0, w_tap = 0, w_kbase = 0, w_step = 0;
+    // k index of the next k-step to request; advances the cursor.  Past the last k-step it keeps returning the last
+    // one: the loads below stay UNCONDITIONAL (a conditionally defined register set is placed in scratch memory by
+    // this compiler - every load then waited for on its own and stored to scratch), the surplus tiles are never written
+    auto next_kidx = [&]() __attribute__((always_inline)) {
+      const int nch = seg_nch(w_seg), ntaps = seg_taps(w_seg);
+      const int kidx = w_kbase + w_tap * nch + w_c;
+      if (w_step + 1 < nsteps) {
         ++w_step;
         if (++w_tap == ntaps) {
           w_tap = 0;
           if (++w_c == nch) { w_c = 0; w_kbase += ntaps * nch; ++w_seg; }
         }
-        return true;
       }
-      return false;
+      return kidx;
+    };
+#define RING_LOAD_W(A, B, C, D)                                             \
+  do {                                                                      \
+    const unsigned char* g_ = wbase + next_kidx() * wstep;                  \
+    A = *reinterpret_cast<const uint4*>(g_);                                \
+    B = *reinterpret_cast<const uint4*>(g_ + 4096);                         \
+    C = *reinterpret_cast<const uint4*>(g_ + 8192);                         \
+    D = *reinterpret_cast<const uint4*>(g_ + 12288);                        \
+  } while (0)
+#define RING_WRITE_W(A, B, C, D, SLOT)                                      \
+  do {                                                                      \
+    unsigned char* l_ = smem + wl_off + (SLOT) * WB;                        \
+    *reinterpret_cast<uint4*>(l_) = A;                                      \
+    *reinterpret_cast<uint4*>(l_ + 4096) = B;                               \
+    *reinterpret_cast<uint4*>(l_ + 8192) = C;                               \
+    *reinterpret_cast<uint4*>(l_ + 12288) = D;                              \
+  } while (0)
+    // interval of k-step s (s % 3 == SL): weights(s + 1) go to their slot, weights(s + 4) are requested into the set
+    // that has just been written out
+    auto weights_interval = [&](auto SL, int s) __attribute__((always_inline)) {
+      constexpr int sl = (decltype(SL)::value + 1) % 3;
+#ifdef RING_X_NOWEIGHTS
+      return;
+#endif
+      const bool wr = s + 1 < nsteps;
+      if constexpr (sl == 0) { if (wr) RING_WRITE_W(wa0, wa1, wa2, wa3, 0); RING_LOAD_W(wa0, wa1, wa2, wa3); }
+      else if constexpr (sl == 1) { if (wr) RING_WRITE_W(wb0_, wb1_, wb2_, wb3_, 1); RING_LOAD_W(wb0_, wb1_, wb2_, wb3_); }
+      else { if (wr) RING_WRITE_W(wc0, wc1, wc2, wc3, 2); RING_LOAD_W(wc0, wc1, wc2, wc3); }
     };
 
-    // patch staging of chunk (s, c) into buffer buf
+    // ---- patch staging of chunk (s, c) through registers
     uint4 preg[NIT];
     float tsc[8], tsh[8];
     bool pcok = true;
@@ -205,127 +223,169 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       const int sg_C = SEG_FIELD(p, s, C), sg_coff = SEG_FIELD(p, s, coff);
       return reinterpret_cast<const T*>(SEG_FIELD(p, s, src)) + img * sg_C + sg_coff + c * KC + chunk16 * VW;
     };
-    auto patch_load_regs = [&](int s, int c) __attribute__((always_inline)) {
-      const int sg_C = SEG_FIELD(p, s, C);
+    // pcok: this thread's 16-byte chunk lies inside the segment - for the patch being transformed / being requested
+    bool pcok_next = true;
+    const T* psrc_next = nullptr;
+    int pC_next = 0;
+    auto patch_request_begin = [&](int s, int c) __attribute__((always_inline)) {
+      pC_next = SEG_FIELD(p, s, C);
       const int cvalid = min(KC, SEG_FIELD(p, s, cin) - c * KC);
-      pcok = pchunk * VW < cvalid;
-      const T* src = patch_src(s, c, pcok ? pchunk : 0);
-#pragma unroll
-      for (int j = 0; j < NIT; ++j) {
-        const T* a = src + (int64_t)max(ppix[j], 0) * sg_C;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(preg[j]) : "v"(a) : "memory");
-      }
+      pcok_next = pchunk * VW < cvalid;
+      psrc_next = patch_src(s, c, pcok_next ? pchunk : 0);
     };
-    auto patch_dma = [&](int s, int c, int buf) __attribute__((always_inline)) {
-      const int sg_C = SEG_FIELD(p, s, C);
-      const int cvalid = min(KC, SEG_FIELD(p, s, cin) - c * KC);
-      const T* src0 = patch_src(s, c, 0);
-      unsigned char* l = smem + buf * PB;
-      const unsigned char* zp = g_ring_zero + (lane & 7) * 16;
-#pragma unroll
-      for (int j = 0; j < NIT; ++j) {
-        // the last piece exists for wave 0 only (rows 320..327); the other waves repeat their piece 9
-        const int jj = (j == NIT - 1 && pw != 0) ? NIT - 2 : j;
-        const int pix = j == NIT - 1 ? (pw != 0 ? ppix[NIT - 2] : ppix[NIT - 1]) : ppix[j];
-        const int ld = j == NIT - 1 ? (pw != 0 ? plds[NIT - 2] : plds[NIT - 1]) : plds[j];
-        const int sch = (ld >> 4) & 7;                       // source chunk = pchunk ^ key
-        const bool ok = pix >= 0 && sch * VW < cvalid;
-        const unsigned char* a = ok ? reinterpret_cast<const unsigned char*>(src0 + (int64_t)pix * sg_C + sch * VW) : zp;
-        __builtin_amdgcn_global_load_lds((gbl_ptr_t)a, (lds_ptr_t)(l + (pw + 4 * jj) * 1024), 16, 0, 0);
-      }
+    auto load_item = [&](auto JJ) __attribute__((always_inline)) {
+      constexpr int j = decltype(JJ)::value;
+      preg[j] = *reinterpret_cast<const uint4*>(psrc_next + (int64_t)max(ppix[j], 0) * pC_next);
     };
     auto load_scale_shift = [&](int s, int c) __attribute__((always_inline)) {
       if constexpr (GNP) {
         const int sgn = s == 0 ? p.seg_gn[0] : s == 1 ? p.seg_gn[1] : s == 2 ? p.seg_gn[2] : p.seg_gn[3];
-        const int gcb = sgn + c * KC + (pcok ? pchunk : 0) * VW;
+        const int gcb = max(sgn, 0) + c * KC + (pcok ? pchunk : 0) * VW;   // (pcok: already this patch's)
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(s_gn + gcb), a1 = *reinterpret_cast<const f32x4*>(s_gn + gcb + 4);
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_gn + gnpad + gcb), b1 = *reinterpret_cast<const f32x4*>(s_gn + gnpad + gcb + 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) { tsc[q] = a0[q]; tsc[4 + q] = a1[q]; tsh[q] = b0[q]; tsh[4 + q] = b1[q]; }
       }
     };
-    auto store_item = [&](auto JJ, int buf) __attribute__((always_inline)) {
+    // GroupNorm + SiLU of item j in place (registers only: this is the part of an interval that runs AFTER its LDS
+    // writes have been issued), and its write one interval later
+    auto xform_item = [&](auto JJ, bool xform) __attribute__((always_inline)) {
       constexpr int j = decltype(JJ)::value;
       uint4 v = preg[j];
-      if constexpr (GNP) v = gn_transform16<T>(v, tsc, tsh, p.gn_silu != 0);
+#ifndef RING_X_NOXFORM
+      if constexpr (GNP) { if (xform) v = gn_transform16<T>(v, tsc, tsh, p.gn_silu != 0); }
+#endif
       if (!(ppix[j] >= 0 && pcok)) v = uint4{0u, 0u, 0u, 0u};            // padding AFTER the activation
-      if (j < NIT - 1 || (ptid >> 3) < PROWS - 32 * (NIT - 1))
-        *reinterpret_cast<uint4*>(smem + buf * PB + plds[j]) = v;
+      preg[j] = v;
     };
-    // the register-staged loads above are invisible to the compiler's own wait bookkeeping: wait by count, and keep
-    // every instruction below the wait (cdna_hip_programming.md 5.7, form iii)
-#define RING_PREG_WAIT(N)                         \
-  do {                                            \
-    RING_WAIT_VM(N);                              \
-    __builtin_amdgcn_sched_barrier(0);            \
-  } while (0)
-
+    auto write_item = [&](auto JJ, int buf) __attribute__((always_inline)) {
+      constexpr int j = decltype(JJ)::value;
+      if (j < NIT - 1 || (ptid >> 3) < PROWS - 32 * (NIT - 1))
+        *reinterpret_cast<uint4*>(smem + buf * PB + plds[j]) = preg[j];
+    };
     auto is_reg = [&](int s) __attribute__((always_inline)) {
       if constexpr (GNP) return (s == 0 ? p.seg_gn[0] : s == 1 ? p.seg_gn[1] : s == 2 ? p.seg_gn[2] : p.seg_gn[3]) >= 0;
       else return false;
     };
+    // 1-tap chunks (raw shortcut segments) read the patch's interior only: item j = interior pixel (ptid / 8 + 32 j),
+    // 8 per thread, in THREE register sets - the patch of tail chunk e is requested two intervals and written one
+    // interval before the chunk's own (single) interval
+    uint4 tp0[8], tp1[8], tp2[8];
+    bool tcok0 = true, tcok1 = true, tcok2 = true;
+    auto tail_load = [&](uint4 (&tp)[8], bool& cok, int s, int c) __attribute__((always_inline)) {
+      const int sg_C = SEG_FIELD(p, s, C);
+      const int cvalid = min(KC, SEG_FIELD(p, s, cin) - c * KC);
+      cok = pchunk * VW < cvalid;
+      const T* src = patch_src(s, c, cok ? pchunk : 0);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = (ptid >> 3) + 32 * j;                    // interior pixel: row r / 16, column r % 16 (always inside the image)
+        tp[j] = *reinterpret_cast<const uint4*>(src + (int64_t)((y0 + (r >> 4)) * W + x0 + (r & 15)) * sg_C);
+      }
+    };
+    auto tail_store = [&](const uint4 (&tp)[8], bool cok, int buf) __attribute__((always_inline)) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = (ptid >> 3) + 32 * j;
+        const int pc = (r & 15) + 1;
+        const int row = ((r >> 4) + 1) * PC + pc;
+        *reinterpret_cast<uint4*>(smem + buf * PB + row * 128 + ((pchunk ^ ((pc >> 1) & 7)) << 4)) = cok ? tp[j] : uint4{0u, 0u, 0u, 0u};
+      }
+    };
 
-    // ---- prologue: the first two weight tiles; patch 0 by LDS-DMA here unless all threads stage it through registers --
+    // ---- prologue: weights 0..3 requested, weights 0 written; patch 0 by all threads -----------------------------
     RSTAMP(33, 256);
-    if (!reg0) patch_dma(0, 0, 0);
-    next_w();
-    next_w();
+    RING_LOAD_W(wa0, wa1, wa2, wa3);
+    RING_LOAD_W(wb0_, wb1_, wb2_, wb3_);
+    RING_LOAD_W(wc0, wc1, wc2, wc3);
     RSTAMP(34, 256);
     if constexpr (GNP) conv_gn_table<512>(p, b, 1, s_gn, gnpad, s_mr, smem + PB);
     RSTAMP(35, 256);
     p0_store();
+    RING_WRITE_W(wa0, wa1, wa2, wa3, 0);
+    RING_LOAD_W(wa0, wa1, wa2, wa3);     // weights(3)
+    {
+      // the patch of chunk 1 (clamped: of chunk 0 again where there is none) is requested now, a whole chunk ahead
+      int s1 = 0, c1 = 1;
+      if (c1 == sg_n0) { c1 = 0; s1 = 1; }
+      if (s1 >= nseg) { s1 = 0; c1 = 0; }
+      patch_request_begin(s1, c1);
+      load_item(std::integral_constant<int, 0>{}); load_item(std::integral_constant<int, 1>{}); load_item(std::integral_constant<int, 2>{});
+      load_item(std::integral_constant<int, 3>{}); load_item(std::integral_constant<int, 4>{}); load_item(std::integral_constant<int, 5>{});
+      load_item(std::integral_constant<int, 6>{}); load_item(std::integral_constant<int, 7>{}); load_item(std::integral_constant<int, 8>{});
+      load_item(std::integral_constant<int, 9>{}); load_item(std::integral_constant<int, 10>{});
+    }
     RSTAMP(36, 256);
-    RING_WAIT_VM(4);                    // patch 0 and weight tile 0 have landed; tile 1 may still be in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // tick(-1)
     RSTAMP(37, 256);
     int pstamp = 38;
     (void)pstamp;
 
-    // ---- main loop over chunks ----------------------------------------------------------------------------------
-    int cs = 0, cc = 0, pb = 0;
-    while (cs < nseg) {
-      const int nch = seg_nch(cs);
-      const int ntaps = seg_taps(cs);
-      int ns = cs, nc = cc + 1;
-      if (nc == nch) { nc = 0; ns = cs + 1; }
+#ifdef RING_X_PRODPRIO
+    __builtin_amdgcn_s_setprio(2);
+#endif
+    // ---- 9-tap chunks --------------------------------------------------------------------------------------------
+    int n9 = 0, n1 = 0;
+    n9 += sg_t0 == 9 ? sg_n0 : 0; n1 += sg_t0 == 1 ? sg_n0 : 0;
+    if (nseg > 1) { n9 += sg_t1 == 9 ? sg_n1 : 0; n1 += sg_t1 == 1 ? sg_n1 : 0; }
+    if (nseg > 2) { n9 += sg_t2 == 9 ? sg_n2 : 0; n1 += sg_t2 == 1 ? sg_n2 : 0; }
+    if (nseg > 3) { n9 += sg_t3 == 9 ? sg_n3 : 0; n1 += sg_t3 == 1 ? sg_n3 : 0; }
+    int cs = 0, cc = 0, pb = 0, sbase = 0;
+    // (ns, nc): the chunk after (cs, cc)
+    auto chunk_after = [&](int s_, int c_, int& ns_, int& nc_) __attribute__((always_inline)) {
+      ns_ = s_; nc_ = c_ + 1;
+      if (nc_ == seg_nch(s_)) { nc_ = 0; ns_ = s_ + 1; }
+    };
+    // An interval = [LDS writes of what was prepared before: weights(s + 1), the patch items transformed in the previous
+    // interval] -> [requests: weights(s + 4), at t = 7 / 8 the patch after the next one] -> [GroupNorm + SiLU of this
+    // interval's items, registers only] -> tick.  The writes come FIRST so that they have completed by the time the
+    // arithmetic is done: with the write at the end of the interval its completion latency (behind the consumers' LDS
+    // reads) sat in front of every tick.  Items: transformed in intervals 0..7 (2,1,1,2,1,1,2,1), written one later.
+    for (int ci = 0; ci < n9; ++ci) {
+      int ns, nc, s2, c2;
+      chunk_after(cs, cc, ns, nc);
+      chunk_after(ns, nc, s2, c2);
       const bool has_next = ns < nseg;
       const bool nreg = has_next && is_reg(ns);
-      // interval t of this chunk = between tick(step - 1) and tick(step)
+      // the patch requested during this chunk's last two intervals: the chunk after the next one (none left: this
+      // chunk's again, dropped)
+      const bool req = s2 < nseg;
+      pcok = pcok_next;
       auto interval = [&](auto TT) __attribute__((always_inline)) {
         constexpr int t = decltype(TT)::value;
-        if (t < ntaps) {
-          const bool wi = next_w();                                  // weight tile two k-steps ahead
-          if constexpr (t == 0) {
-            if (has_next) { if (nreg) patch_load_regs(ns, nc); else patch_dma(ns, nc, pb ^ 1); }
-          } else if (nreg) {
-            if constexpr (t == 1) {
-              // the patch loads were issued before the previous tick's weight tile and this one's
-              if (wi) RING_PREG_WAIT(4); else RING_PREG_WAIT(0);
-              load_scale_shift(ns, nc);
-            }
-            if constexpr (t == 1) { store_item(std::integral_constant<int, 0>{}, pb ^ 1); store_item(std::integral_constant<int, 1>{}, pb ^ 1); }
-            if constexpr (t == 2) { store_item(std::integral_constant<int, 2>{}, pb ^ 1); store_item(std::integral_constant<int, 3>{}, pb ^ 1); }
-            if constexpr (t == 3) { store_item(std::integral_constant<int, 4>{}, pb ^ 1); store_item(std::integral_constant<int, 5>{}, pb ^ 1); }
-            if constexpr (t == 4) store_item(std::integral_constant<int, 6>{}, pb ^ 1);
-            if constexpr (t == 5) store_item(std::integral_constant<int, 7>{}, pb ^ 1);
-            if constexpr (t == 6) store_item(std::integral_constant<int, 8>{}, pb ^ 1);
-            if constexpr (t == 7) store_item(std::integral_constant<int, 9>{}, pb ^ 1);
-            if constexpr (t == 8) store_item(std::integral_constant<int, 10>{}, pb ^ 1);
-          }
-          // everything issued before this interval has to have landed; of this interval's own operations the
-          // weight tile (4, issued first) may stay in flight, and so may the next patch (11, issued after it) unless
-          // this is the chunk's only interval
-          if constexpr (t == 0) {
-            if (has_next && ntaps == 9) { if (wi) RING_WAIT_VM(15); else RING_WAIT_VM(11); }
-            else if (has_next) RING_WAIT_VM(0);
-            else { if (wi) RING_WAIT_VM(4); else RING_WAIT_VM(0); }
-          } else {
-            if (wi) RING_WAIT_VM(4); else RING_WAIT_VM(0);
-          }
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();   // tick
+        weights_interval(std::integral_constant<int, t % 3>{}, sbase + t);
+        if (has_next) {
+          if constexpr (t == 1) { write_item(std::integral_constant<int, 0>{}, pb ^ 1); write_item(std::integral_constant<int, 1>{}, pb ^ 1); }
+          if constexpr (t == 2) write_item(std::integral_constant<int, 2>{}, pb ^ 1);
+          if constexpr (t == 3) write_item(std::integral_constant<int, 3>{}, pb ^ 1);
+          if constexpr (t == 4) { write_item(std::integral_constant<int, 4>{}, pb ^ 1); write_item(std::integral_constant<int, 5>{}, pb ^ 1); }
+          if constexpr (t == 5) write_item(std::integral_constant<int, 6>{}, pb ^ 1);
+          if constexpr (t == 6) write_item(std::integral_constant<int, 7>{}, pb ^ 1);
+          if constexpr (t == 7) { write_item(std::integral_constant<int, 8>{}, pb ^ 1); write_item(std::integral_constant<int, 9>{}, pb ^ 1); }
+          if constexpr (t == 8) write_item(std::integral_constant<int, 10>{}, pb ^ 1);
         }
+        // (unconditional loads, see next_kidx)
+        if constexpr (t == 7) {
+          patch_request_begin(req ? s2 : cs, req ? c2 : cc);
+          load_item(std::integral_constant<int, 0>{}); load_item(std::integral_constant<int, 1>{}); load_item(std::integral_constant<int, 2>{});
+          load_item(std::integral_constant<int, 3>{}); load_item(std::integral_constant<int, 4>{}); load_item(std::integral_constant<int, 5>{});
+          load_item(std::integral_constant<int, 6>{}); load_item(std::integral_constant<int, 7>{});
+        }
+        if constexpr (t == 8) {
+          load_item(std::integral_constant<int, 8>{}); load_item(std::integral_constant<int, 9>{}); load_item(std::integral_constant<int, 10>{});
+        }
+        if constexpr (t == 0) { if (nreg) load_scale_shift(ns, nc); }
+        if constexpr (t == 0) { xform_item(std::integral_constant<int, 0>{}, nreg); xform_item(std::integral_constant<int, 1>{}, nreg); }
+        if constexpr (t == 1) xform_item(std::integral_constant<int, 2>{}, nreg);
+        if constexpr (t == 2) xform_item(std::integral_constant<int, 3>{}, nreg);
+        if constexpr (t == 3) { xform_item(std::integral_constant<int, 4>{}, nreg); xform_item(std::integral_constant<int, 5>{}, nreg); }
+        if constexpr (t == 4) xform_item(std::integral_constant<int, 6>{}, nreg);
+        if constexpr (t == 5) xform_item(std::integral_constant<int, 7>{}, nreg);
+        if constexpr (t == 6) { xform_item(std::integral_constant<int, 8>{}, nreg); xform_item(std::integral_constant<int, 9>{}, nreg); }
+        if constexpr (t == 7) xform_item(std::integral_constant<int, 10>{}, nreg);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // tick
       };
       interval(std::integral_constant<int, 0>{}); interval(std::integral_constant<int, 1>{});
       interval(std::integral_constant<int, 2>{}); interval(std::integral_constant<int, 3>{});
@@ -334,12 +394,50 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       interval(std::integral_constant<int, 8>{});
       pb ^= 1;
       cs = ns; cc = nc;
+      sbase += 9;
       RSTAMP(pstamp, 256);
       if (pstamp < 60) ++pstamp;
     }
+    // ---- 1-tap chunks: tail chunk e runs in interval e; its interval writes the patch of chunk e + 1 (set (e+1) % 3,
+    // requested one interval earlier) into the other buffer and requests the patch of chunk e + 2 (set (e+2) % 3).
+    // The patch of tail chunk 1 is requested here (one exposed load latency per launch, instead of three more register
+    // sets alive across the whole 9-tap loop); every request is unconditional, clamped to an existing chunk.
+    {
+      int s1 = cs, c1 = cc;
+      if (n1 >= 2) chunk_after(cs, cc, s1, c1);
+      tail_load(tp1, tcok1, min(s1, nseg - 1), s1 < nseg ? c1 : 0);
+      tail_load(tp2, tcok2, min(s1, nseg - 1), s1 < nseg ? c1 : 0);
+      tail_load(tp0, tcok0, min(s1, nseg - 1), s1 < nseg ? c1 : 0);
+    }
+    for (int e0 = 0; e0 < n1; e0 += 3) {
+      auto tail_interval = [&](auto EE) __attribute__((always_inline)) {
+        constexpr int em = decltype(EE)::value;        // e % 3
+        const int e = e0 + em;
+        if (e < n1) {
+          weights_interval(std::integral_constant<int, em>{}, sbase + e);
+          int s1, c1, s2, c2;
+          chunk_after(cs, cc, s1, c1);
+          chunk_after(s1, c1, s2, c2);
+          if (e + 1 < n1) {
+            if constexpr (em == 0) tail_store(tp1, tcok1, pb ^ 1); else if constexpr (em == 1) tail_store(tp2, tcok2, pb ^ 1); else tail_store(tp0, tcok0, pb ^ 1);
+          }
+          {
+            const bool more = e + 2 < n1;
+            const int sl = more ? s2 : cs, cl = more ? c2 : cc;
+            if constexpr (em == 0) tail_load(tp2, tcok2, sl, cl); else if constexpr (em == 1) tail_load(tp0, tcok0, sl, cl); else tail_load(tp1, tcok1, sl, cl);
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();   // tick
+          pb ^= 1;
+          cs = s1; cc = c1;
+        }
+      };
+      tail_interval(std::integral_constant<int, 0>{});
+      tail_interval(std::integral_constant<int, 1>{});
+      tail_interval(std::integral_constant<int, 2>{});
+    }
     if (p.stat_out) __builtin_amdgcn_s_barrier();     // the consumers' statistics exchange
     return;
-#undef RING_PREG_WAIT
   }
 
   // ============================================ CONSUMERS ============================================
@@ -374,7 +472,11 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
+#ifdef RING_X_NOMFMA
+      asm volatile("" :: "v"(fa[0].x), "v"(fa[1].x), "v"(fa[2].x), "v"(fa[3].x), "v"(fb[i].x), "v"(fb[i].w));
+#else
       for (int j = 0; j < 4; ++j) Mfma<T>::run(fa[j], fb[i], acc[j][i]);
+#endif
       fb[i] = *reinterpret_cast<const uint4*>(smem + pnext + i * (PC * 128));
     }
     // pinned issue order = the source order above: the 4 weight reads beside row 0's MFMAs, then every row's refill
@@ -408,7 +510,10 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
   __builtin_amdgcn_s_barrier();           // tick(-1): patch 0 and weight tile 0 are in LDS
   RSTAMP(3, 0);
   __builtin_amdgcn_sched_barrier(0);
+#if defined(RING_X_NOPRIO) || defined(RING_X_PRODPRIO)
+#else
   __builtin_amdgcn_s_setprio(2);
+#endif
 
   // The 9-tap chunks come first (fdbm_conv_ring_ok), then the 1-tap ones: two loops one after the other, so the 128
   // accumulator registers are carried through straight-line loop bodies and stay in place.  In the 9-tap loop every
@@ -652,7 +757,13 @@ static int launch_ring(const ConvParams& p, hipStream_t st) {
   }
   const int tiles_x = p.W / 16, tiles_y = p.H / 16;
   dim3 grid((unsigned)(p.B * tiles_x * tiles_y), (unsigned)((p.Cout + 127) / 128));
+#ifdef FDBM_STAMPS
+  ConvParams pd = p;
+  { const char* e = getenv("FDBM_RING_DBG"); pd.ksplit = e ? atoi(e) : 0; }
+  conv_ring_kernel<T, TO, GNP><<<grid, 512, SMEM, st>>>(pd, tiles_x, tiles_y);
+#else
   conv_ring_kernel<T, TO, GNP><<<grid, 512, SMEM, st>>>(p, tiles_x, tiles_y);
+#endif
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm(ring)");
   return 0;
 }

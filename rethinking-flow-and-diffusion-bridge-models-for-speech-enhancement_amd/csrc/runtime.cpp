@@ -16,9 +16,11 @@ void fdbm_set_error(const char* fmt, ...) {
 extern "C" const char* fdbm_last_error(void) { return g_err; }
 extern "C" int fdbm_version(void) { return 1; }
 
-// A kernel of our own, not hipMemsetAsync: inside a replayed HIP graph the runtime's memset node stopped
-// zeroing after an unrelated synchronous device-to-host copy in the same process (ROCm 7.2; the statistics
-// arena then accumulated across forwards) - a plain kernel node has no such dependence on runtime state.
+// A kernel of our own, not hipMemsetAsync: a memset node captured into a HIP graph zeroes on the FIRST replay only
+// (ROCm 7.2, gfx950; tools/memset_node_repro.py, profiles/r02/memset_node_repro.txt: { memset(buf) ; buf += 1 }
+// reads 1.0 after replay 1 and (1.0 .. inf) after every later one, for 64-byte and 412-KiB nodes alike, with or
+// without host copies in between; a 2-MiB node and a kernel node are correct).  The statistics arena was such a
+// node in round 1: from the second replay on it was filled with a non-zero pattern and every result was NaN.
 __global__ void __launch_bounds__(256) zero_kernel(uint4* __restrict__ p, int64_t n16, unsigned char* __restrict__ tail,
                                                    int ntail) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256)
@@ -207,19 +209,16 @@ extern "C" void fdbm_ncsnpp_destroy(fdbm_ncsnpp_ctx* c) {
 extern "C" int fdbm_ncsnpp_forward(fdbm_ncsnpp_ctx* c, const void* x, const void* y, const float* log_t,
                                    void* out, void* stream) {
   FDBM_CHECK(c && x && y && log_t && out, "fdbm_ncsnpp_forward: null argument");
-  hipStream_t st = (hipStream_t)stream;
-  const size_t nb = (size_t)c->n_complex * 8;
-  hipError_t e = hipSuccess;
-  if (x != c->x_in) e = hipMemcpyAsync(c->x_in, x, nb, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess && y != c->y_in) e = hipMemcpyAsync(c->y_in, y, nb, hipMemcpyDeviceToDevice, st);
-  if (e == hipSuccess && log_t != c->logt_in)
-    e = hipMemcpyAsync(c->logt_in, log_t, sizeof(float) * (size_t)c->B, hipMemcpyDeviceToDevice, st);
-  FDBM_CHECK(e == hipSuccess, "fdbm_ncsnpp_forward: input copy failed: %s", hipGetErrorString(e));
-  const int rc = fdbm_run_program(c->ops, c->n_ops, stream);
+  // copies by the library's own kernel (not hipMemcpyAsync): a caller may capture this entry into a HIP graph, and
+  // the runtime's copy / memset graph nodes are what broke in round 1 (see zero_kernel above)
+  const int64_t nf = (int64_t)c->n_complex * 2;
+  int rc = 0;
+  if (x != c->x_in) rc = fdbm_copy_f32((float*)c->x_in, (const float*)x, nf, stream);
+  if (!rc && y != c->y_in) rc = fdbm_copy_f32((float*)c->y_in, (const float*)y, nf, stream);
+  if (!rc && log_t != c->logt_in) rc = fdbm_copy_f32(c->logt_in, (const float*)log_t, (int64_t)c->B, stream);
   if (rc) return rc;
-  if (out != c->s_out) {
-    e = hipMemcpyAsync(out, c->s_out, nb, hipMemcpyDeviceToDevice, st);
-    FDBM_CHECK(e == hipSuccess, "fdbm_ncsnpp_forward: output copy failed: %s", hipGetErrorString(e));
-  }
-  return 0;
+  rc = fdbm_run_program(c->ops, c->n_ops, stream);
+  if (rc) return rc;
+  if (out != c->s_out) rc = fdbm_copy_f32((float*)out, (const float*)c->s_out, nf, stream);
+  return rc;
 }

@@ -54,7 +54,7 @@ class SpecFrontend:
             return 1
         return t
 
-    def _stft_call(self, sig, Tpad, pad_mode, fused):
+    def _stft_call(self, sig, Tpad, pad_mode, fused, norm=None):
         lead = sig.shape[:-1]
         L = sig.shape[-1]
         x = sig.reshape(-1, L).to(self.device, torch.float32).contiguous()
@@ -62,10 +62,25 @@ class SpecFrontend:
         frames = 1 + L // self.hop_length
         Tpad = Tpad or frames
         out = torch.empty(B, self.bins, Tpad, dtype=torch.complex64, device=self.device)
-        hip.call("fdbm_stft", hip.ptr(out), hip.ptr(x), hip.ptr(self.window), B, L, self.n_fft,
-                 self.hop_length, frames, Tpad, pad_mode, self._tcode(fused), self.spec_factor,
-                 self.spec_abs_exponent)
+        if norm is None:
+            hip.call("fdbm_stft", hip.ptr(out), hip.ptr(x), hip.ptr(self.window), B, L, self.n_fft,
+                     self.hop_length, frames, Tpad, pad_mode, self._tcode(fused), self.spec_factor,
+                     self.spec_abs_exponent)
+        else:
+            assert norm.numel() == B and norm.dtype == torch.float32 and norm.is_cuda
+            hip.call("fdbm_stft_norm", hip.ptr(out), hip.ptr(x), hip.ptr(self.window), hip.ptr(norm), B, L, self.n_fft,
+                     self.hop_length, frames, Tpad, pad_mode, self._tcode(fused), self.spec_factor,
+                     self.spec_abs_exponent)
         return out.reshape(*lead, self.bins, Tpad)
+
+    def norm_factor(self, sig):
+        """Per-clip normalisation factor of the drivers (infer_folder.py:102-107): max |y| for normalize == "noisy",
+        torch.std(y) for "std".  -> f32 [B] on the device."""
+        x = sig.reshape(-1, sig.shape[-1]).to(self.device, torch.float32).contiguous()
+        nf = torch.empty(x.shape[0], dtype=torch.float32, device=self.device)
+        mode = {"noisy": 0, "std": 1}[self.normalize]
+        hip.call("fdbm_wave_norm_factor", hip.ptr(nf), hip.ptr(x), x.shape[0], x.shape[1], mode)
+        return nf
 
     # ---- reference-named pieces -------------------------------------------------------
     def stft(self, sig):
@@ -96,16 +111,16 @@ class SpecFrontend:
         return out
 
     # ---- fused forms used by the drivers ------------------------------------------------
-    def spec_forward_padded(self, sig, pad_mode="reflection"):
-        """[B, L] (or [L]) waveform -> complex64 [B,1,bins,Tpad]: stft + spec_fwd + pad_spec
-        (infer_folder.py:110-112) in one launch.  pad_mode None: no padding."""
+    def spec_forward_padded(self, sig, pad_mode="reflection", norm=None):
+        """[B, L] (or [L]) waveform -> complex64 [B,1,bins,Tpad]: [y / norm +] stft + spec_fwd + pad_spec
+        (infer_folder.py:106-112) in one launch.  pad_mode None: no padding; norm: f32 [B] from norm_factor()."""
         sig2 = sig.reshape(-1, sig.shape[-1])
         frames = 1 + sig2.shape[-1] // self.hop_length
         Tpad = frames + ((64 - frames % 64) % 64 if pad_mode else 0)
-        Y = self._stft_call(sig2, Tpad, _PAD.get(pad_mode, 0), fused=True)
+        Y = self._stft_call(sig2, Tpad, _PAD.get(pad_mode, 0), fused=True, norm=norm)
         return Y[:, None]
 
-    def _istft_call(self, spec, length, fused):
+    def _istft_call(self, spec, length, fused, norm=None, clip=0.0):
         spec = spec.to(self.device)
         lead = spec.shape[:-2]
         bins, Tp = spec.shape[-2], spec.shape[-1]
@@ -116,11 +131,19 @@ class SpecFrontend:
             length = self.hop_length * (Tp - 1)
         ws = torch.empty(B, Tp, self.n_fft, device=self.device)
         out = torch.empty(B, length, device=self.device)
-        hip.call("fdbm_istft", hip.ptr(out), hip.ptr(s), hip.ptr(self.window), hip.ptr(ws), B, length,
-                 self.n_fft, self.hop_length, Tp, Tp, self._tcode(fused), self.spec_factor,
-                 self.spec_abs_exponent)
+        if norm is None:
+            hip.call("fdbm_istft", hip.ptr(out), hip.ptr(s), hip.ptr(self.window), hip.ptr(ws), B, length,
+                     self.n_fft, self.hop_length, Tp, Tp, self._tcode(fused), self.spec_factor,
+                     self.spec_abs_exponent)
+        else:
+            assert norm.numel() == B and norm.dtype == torch.float32 and norm.is_cuda
+            peak = torch.empty(B, dtype=torch.float32, device=self.device)
+            hip.call("fdbm_istft_renorm", hip.ptr(out), hip.ptr(s), hip.ptr(self.window), hip.ptr(ws), hip.ptr(norm),
+                     hip.ptr(peak), float(clip), B, length, self.n_fft, self.hop_length, Tp, Tp, self._tcode(fused),
+                     self.spec_factor, self.spec_abs_exponent)
         return out.reshape(*lead, length)
 
-    def to_audio(self, spec, length=None):
-        """spec_back + istft (model.py:376-377)."""
-        return self._istft_call(spec, length, fused=True)
+    def to_audio(self, spec, length=None, norm=None, clip=0.0):
+        """spec_back + istft (model.py:376-377) [+ x_hat * norm and the drivers' clip rule: if max |x_hat| > 1 then
+        x_hat / max |x_hat| * clip (0.95 infer_folder.py:121, 0.5 infer_single.py:99); norm: f32 [B]]."""
+        return self._istft_call(spec, length, fused=True, norm=norm, clip=clip)

@@ -77,13 +77,16 @@ _SIGS = {
     "fdbm_attention": [c_void_p, c_void_p] + [c_int] * 4,
     "fdbm_stft": [c_void_p] * 3 + [c_int] * 8 + [c_float, c_float],
     "fdbm_istft": [c_void_p] * 4 + [c_int] * 7 + [c_float, c_float],
+    "fdbm_wave_norm_factor": [c_void_p, c_void_p, c_int, c_int, c_int],
+    "fdbm_stft_norm": [c_void_p] * 4 + [c_int] * 8 + [c_float, c_float],
+    "fdbm_istft_renorm": [c_void_p] * 6 + [c_float] + [c_int] * 7 + [c_float, c_float],
     "fdbm_spec_transform": [c_void_p, c_void_p, c_i64, c_int, c_float, c_float, c_int],
     "fdbm_pad_spec": [c_void_p, c_void_p, c_i64, c_int, c_int, c_int],
     "fdbm_memset_zero": [c_void_p, c_i64],
     "fdbm_run_program": [ctypes.POINTER(Op), c_int],
 }
 EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan",
-                                "fdbm_conv_plan_ex", "fdbm_conv_policy", "fdbm_runtime_init_side", "fdbm_ncsnpp_create", "fdbm_ncsnpp_destroy",
+                                "fdbm_conv_plan_ex", "fdbm_conv_policy", "fdbm_conv_last_kind", "fdbm_runtime_init_side", "fdbm_ncsnpp_create", "fdbm_ncsnpp_destroy",
                                 "fdbm_ncsnpp_forward"])
 
 
@@ -113,6 +116,8 @@ def lib():
         L.fdbm_runtime_init_side.restype = c_int
         L.fdbm_conv_policy.argtypes = [c_int]
         L.fdbm_conv_policy.restype = c_int
+        L.fdbm_conv_last_kind.argtypes = []
+        L.fdbm_conv_last_kind.restype = c_int
         L.fdbm_ncsnpp_create.argtypes = [ctypes.POINTER(Op), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_i64, c_int]
         L.fdbm_ncsnpp_create.restype = c_void_p
         L.fdbm_ncsnpp_destroy.argtypes = [c_void_p]

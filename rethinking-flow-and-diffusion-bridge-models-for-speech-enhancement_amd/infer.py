@@ -106,17 +106,23 @@ class Enhancer:
         if y.dim() == 1:
             y = y[None]
         T_orig = y.shape[-1]
-        if self.normalize == "std":
-            norm = y.std()
-        else:
-            norm = y.abs().max()
-        y = (y / norm).to(self.device)
-        Y = self.fe.spec_forward_padded(y, self.pad_mode)                 # [C,1,F,Tpad]; channels ride as the batch
+        y = y.to(self.device)
+        self.fe.normalize = self.normalize
+        # one factor for the whole file (infer_folder.py:102-107 reduce over every channel); the channels ride as the
+        # batch.  Mono: the kernels' per-row factor IS the file's; more channels: the rows' maximum ("noisy") or the
+        # file's standard deviation ("std") broadcast to every row
+        nf = self.fe.norm_factor(y)
+        if y.shape[0] > 1:
+            nf = (nf.max() if self.normalize != "std" else y.std()).expand(y.shape[0]).contiguous()
+        Y = self.fe.spec_forward_padded(y, self.pad_mode, norm=nf)        # [C,1,F,Tpad]
         sample = self.bridge.sampler(self.net, Y, **self.sampler_kwargs)
-        x_hat = self.fe.to_audio(sample[:, 0], T_orig) * norm.to(self.device)
-        peak = x_hat.abs().max()
-        if peak > 1.0:
-            x_hat = x_hat / peak * clip
+        if y.shape[0] == 1:
+            x_hat = self.fe.to_audio(sample[:, 0], T_orig, norm=nf, clip=clip)       # renormalise + clip rule fused
+        else:
+            x_hat = self.fe.to_audio(sample[:, 0], T_orig, norm=nf)
+            peak = x_hat.abs().max()                                                  # over all channels (infer_folder.py:119-121)
+            if peak > 1.0:
+                x_hat = x_hat / peak * clip
         return x_hat.cpu().numpy()
 
 

@@ -348,7 +348,7 @@ def gen_teacher(n_steps=30):
 
 
 def gen_contractive(n_steps=30):
-    """Free-running N=30 ode_ei at the BASELINE geometry with the 'contractive' weight profile (output layer x0.03):
+    """Free-running N=30 ode_ei at the BASELINE geometry with the 'contractive' weight profile (output layer x0.01):
     the sampler does not amplify rounding noise, so two fp32 evaluations CAN agree to 1e-4 end to end.  The
     reference's own spread (8 vs 3 threads) is stored beside the result as the noise floor."""
     from fdbm.bridge import Bridge

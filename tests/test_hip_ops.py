@@ -623,3 +623,34 @@ def test_frontend(golden, tag, n_fft, hop, window):
     assert (x2.cpu() - ref2).abs().max() < 1e-5
     n_safe = (wave.shape[-1] // hop - 1) * hop        # samples no pad frame touches
     assert (x2.cpu()[..., :n_safe] - wave.cpu()[..., :n_safe]).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("normalize", ["noisy", "std"])
+@pytest.mark.parametrize("clip,gain", [(0.95, 3.0), (0.5, 3.0), (0.95, 0.2)])
+def test_waveform_normalisation_fused(golden, normalize, clip, gain):
+    """Row a1: normalise / renormalise / clip rule (infer_folder.py:102-107,118-121; infer_single.py:97-99) fused into the
+    STFT and iSTFT launches, against the CPU oracle: the factor, the spectrogram of y / nf, and x_hat * nf with the
+    0.95 / 0.5 rule both when it triggers (peak > 1) and when it does not."""
+    from fdbm_amd.frontend import SpecFrontend
+    from oracle import frontend as ofe
+    g = golden("frontend_512")
+    wave = torch.from_numpy(g["wave"]) * gain                      # [1, L]
+    fe = SpecFrontend(n_fft=512, hop_length=256, window="sqrthann", normalize=normalize, device=DEV)
+    nf_ref = ofe.norm_factor(wave, normalize)
+    nf = fe.norm_factor(wave.to(DEV))
+    assert abs(nf.item() - nf_ref.item()) <= 2e-7 * nf_ref.item()
+    nf_exact = torch.full((1,), float(nf_ref), device=DEV)
+    Y = fe.spec_forward_padded(wave.to(DEV), "reflection", norm=nf_exact)
+    Yref = ofe.pad_spec(ofe.spec_fwd(ofe.stft(wave / nf_ref))[:, None], "reflection")
+    assert (Y.cpu() - Yref).abs().max() < 2e-5
+    # back: a spectrogram whose waveform peaks above 1 after renormalisation iff gain > 1
+    x = fe.to_audio(Yref[:, 0].to(DEV), wave.shape[-1], norm=nf_exact, clip=clip).cpu()
+    xref = ofe.renormalize(ofe.istft(ofe.spec_back(Yref[:, 0]), wave.shape[-1]), nf_ref, clip)
+    assert (gain > 1) == bool(abs(xref.abs().max().item() - clip) < 1e-5)
+    assert (x - xref).abs().max() < 5e-6 * max(1.0, gain)
+    # two clips of a batch keep their own factors
+    w2 = torch.cat([wave, 0.5 * wave.flip(-1)], 0).to(DEV)
+    nf2 = fe.norm_factor(w2)
+    assert abs(nf2[1].item() - ofe.norm_factor(0.5 * wave.flip(-1), normalize).item()) <= 2e-7 * nf2[1].item()
+    x2 = fe.to_audio(fe.spec_forward_padded(w2, "reflection", norm=nf2)[:, 0], w2.shape[-1], norm=nf2, clip=clip).cpu()
+    assert (x2[0] - x[0]).abs().max() < 2e-5 * max(1.0, gain)

@@ -21,7 +21,7 @@ def run(B, cins, short, **feat):
     torch.cuda.synchronize()
     a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); hip.call("fdbm_conv_igemm", ca); b_.record(); torch.cuda.synchronize()
-    s = ws.view(torch.int64)[:64].cpu().tolist()
+    s = ws.view(torch.int64)[:128].cpu().tolist()
     t0 = min(s[0], s[32])
     ns = (s[31] - s[30]) * 10.0 / max(1, s[22] - s[0])
     print(f"B{B} {cins}+{short} {feat}: launch {a.elapsed_time(b_) * 1e3:.1f} us, shader clock {1e3 / ns:.0f} MHz")
@@ -33,9 +33,16 @@ def run(B, cins, short, **feat):
     for i in range(32, 62):
         if s[i]:
             print(f"   P {pn.get(i, f'chunk {i - 38} done'):22s} {(s[i] - t0) * ns:9.0f} ns")
+    if s[64]:
+        print("   P chunk 1 intervals: start | work done | waits done | tick passed (ns)")
+        for t in range(9):
+            print("     t=%d " % t + " ".join(f"{(s[64 + 4 * t + k] - t0) * ns:8.0f}" for k in range(4)))
 
 
-run(1, [128], [])
-run(1, [128], [], gn=True, stat=True, res=True)
-run(1, [256], [], gn=True)
-run(1, [128], [128, 128], gn=True, stat=True, res=True)
+if len(sys.argv) > 1:
+    run(1, [256], [], gn=True)
+else:
+    run(1, [128], [])
+    run(1, [128], [], gn=True, stat=True, res=True)
+    run(1, [256], [], gn=True)
+    run(1, [128], [128, 128], gn=True, stat=True, res=True)

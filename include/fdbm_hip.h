@@ -26,6 +26,7 @@ extern "C" {
 
 #define FDBM_F32 0
 #define FDBM_BF16 1
+#define FDBM_F16 2      /* IEEE half storage, fp32 accumulation (BASELINE configs[4]); every entry that takes FDBM_BF16 takes it */
 
 #define FDBM_MAX_SEG 4
 
@@ -55,6 +56,13 @@ int fdbm_pc_corrector(void* x_new, void* x_mean, const void* x, const void* s, c
                       const void* noise, const float* a, const float* b, const float* den,
                       const float* step, const float* noise_scale, int B, int64_t n_complex,
                       void* stream);
+
+/* Langevin corrector's step size on the device (fdbm/util/correctors.py:46-51): step[b] = (snr * mean_b ||noise_b|| /
+ * (mean_b ||score_b|| + 1e-8))^2 * 2, noise_scale[b] = sqrt(step * 2), score as in fdbm_pc_corrector.  Two launches,
+ * no host round trip (graph-capturable); scratch: B * 128 doubles. */
+int fdbm_langevin_step(float* step /*[B]*/, float* noise_scale /*[B]*/, void* scratch, const void* x, const void* s,
+                       const void* y, const void* noise, const float* a, const float* b, const float* den,
+                       float snr, int B, int64_t n_complex, void* stream);
 
 /* ------------------------------------------------------------------ network input / output
  * cat(x.re, x.im, y.re, y.im) with the Nyquist row dropped when F == 257
@@ -171,8 +179,8 @@ typedef struct {
   float scale;          /* 1/sqrt(2) with skip_rescale, else 1                      */
   void* out;            /* [M][Cout] dtype dt_out                                   */
   int32_t B, H, W, Cout, CoutPad;
-  int32_t dt_in;        /* FDBM_F32 | FDBM_BF16 : sources and packed weights        */
-  int32_t dt_out;       /* FDBM_F32 | FDBM_BF16 (f32 out with bf16 in is allowed)   */
+  int32_t dt_in;        /* FDBM_F32 | FDBM_BF16 | FDBM_F16 : sources and packed weights */
+  int32_t dt_out;       /* FDBM_F32, or dt_in (f32 out with 16-bit in is allowed)   */
   void* workspace;      /* optional split-K scratch (fp32 slabs) or NULL            */
   int64_t workspace_bytes;
   /* optional GroupNorm(+SiLU) prologue: act(gn(x)) is applied to the segments selected by

@@ -249,10 +249,15 @@ class Bridge:
         The default predictor name is unregistered in the reference too, so it
         raises ValueError exactly there; pass 'euler_maruyama' (SURVEY.md 7.1)."""
         noise = self._noise(y, kwargs)
-        kwargs.pop("use_graph", None)
+        use_graph = kwargs.pop("use_graph", True)
         predictor = PredictorRegistry.get_by_name(predictor_name)(self, model)
         corrector = CorrectorRegistry.get_by_name(corrector_name)(self, model, snr=snr,
                                                                  n_steps=corrector_steps)
+        if (use_graph and y.is_cuda and getattr(model, "sample_graph", None) is not None and hasattr(self.path, "sde_weights")
+                and predictor_name in ("euler_maruyama", "none") and corrector_name in ("ald", "langevin", "none")
+                and not (predictor_name == "none" and corrector_name == "none")):
+            from .engine import pc_with_graph
+            return pc_with_graph(model, self, y, noise, predictor_name, corrector_name, snr, corrector_steps, denoise)
         predictor.noise = corrector.noise = noise
         with torch.no_grad():
             xt = self.prior_sampling(y, noise)

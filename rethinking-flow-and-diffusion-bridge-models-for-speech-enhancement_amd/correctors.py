@@ -53,9 +53,15 @@ class LangevinCorrector(Corrector):
         for _ in range(self.n_steps):
             s = self.model(x, y, t_host.to(x.device))
             a_t, b_t, den = self._score_terms(t_host)
+            noise = self._randn(x)
+            if x.is_cuda:
+                # norms, step size and noise scale stay on the device (fdbm_langevin_step): no synchronisation
+                from . import hip
+                step, nscale = hip.langevin_step(x, s, y, noise, a_t, b_t, den, self.snr)
+                x, x_mean = hip.pc_corrector(x, s, y, noise, a_t, b_t, den, step, nscale)
+                continue
             e = lambda w: w.to(x.device)[:, None, None, None]
             score = - (x - (e(a_t) * s + e(b_t) * y)) / e(den)
-            noise = self._randn(x)
             g_norm = torch.norm(score.reshape(score.shape[0], -1), dim=-1).mean()
             n_norm = torch.norm(noise.reshape(noise.shape[0], -1), dim=-1).mean()
             step = ((self.snr * n_norm / (g_norm + 1e-8)) ** 2 * 2).unsqueeze(0).cpu()

@@ -121,8 +121,8 @@ __global__ void __launch_bounds__(256) attention_kernel(T* __restrict__ out, con
       if (sl < nslab && sl * 64 + tj * 4 < C) {
         const float r4[4] = {o[sl * 4] * inv, o[sl * 4 + 1] * inv, o[sl * 4 + 2] * inv, o[sl * 4 + 3] * inv};
         if constexpr (sizeof(T) == 2) {
-          bf16x4 t = {(bf16_t)r4[0], (bf16_t)r4[1], (bf16_t)r4[2], (bf16_t)r4[3]};
-          *reinterpret_cast<bf16x4*>(dst + sl * 64 + tj * 4) = t;
+          typename V16<T>::x4 t = {(T)r4[0], (T)r4[1], (T)r4[2], (T)r4[3]};
+          *reinterpret_cast<typename V16<T>::x4*>(dst + sl * 64 + tj * 4) = t;
         } else {
           *reinterpret_cast<f32x4*>(dst + sl * 64 + tj * 4) = f32x4{r4[0], r4[1], r4[2], r4[3]};
         }
@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(256) attention_kernel(T* __restrict__ out, con
 
 // LDS rows: K tile [64 keys][C bf16 + 16 B pad]; V^T tile [C channels][64 keys bf16 + 16 B pad], its
 // 16-byte slots (8 keys) XOR-swizzled with (channel >> 3) & 7; scores [16][N] f32; P [16][N bf16 + 16 B].
-__global__ void __launch_bounds__(256) attention_mfma_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ qkv,
+template <typename H>
+__global__ void __launch_bounds__(256) attention_mfma_kernel(H* __restrict__ out, const H* __restrict__ qkv,
                                                              int N, int C, float scale) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
   const int KRS = C * 2 + 16;                 // K-tile row stride (bytes)
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(bf16_t* __restrict_
   const int q0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fk = lane >> 4;
-  const bf16_t* base = qkv + (int64_t)b * N * 3 * C;
+  const H* base = qkv + (int64_t)b * N * 3 * C;
   const int nch = C / 8;                      // 16-byte chunks per row
   const int nks = C / 32;                     // MFMA k-steps over the channels (<= 8)
 
@@ -177,7 +178,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(bf16_t* __restrict_
     for (int ks = 0; ks < 8; ++ks)
       if (ks < nks) {
         const uint4 kf = *reinterpret_cast<const uint4*>(s_kv + (wave * 16 + frow) * KRS + (ks * 4 + fk) * 16);
-        Mfma<bf16_t>::run(kf, qf[ks], acc);      // rows = keys, columns = queries
+        Mfma<H>::run(kf, qf[ks], acc);      // rows = keys, columns = queries
       }
     // lane (query frow, fk) holds keys k0 + 16 wave + 4 fk + 0..3
     *reinterpret_cast<f32x4*>(s_S + frow * N + k0 + wave * 16 + fk * 4) = acc * scale;
@@ -198,8 +199,8 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(bf16_t* __restrict_
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) l += __shfl_xor(l, off);
     const float inv = 1.0f / l;
-    bf16_t* prow = reinterpret_cast<bf16_t*>(s_P + q * PRS) + part * per;
-    for (int i = 0; i < per; ++i) prow[i] = (bf16_t)(__expf(row[i] - m) * inv);
+    H* prow = reinterpret_cast<H*>(s_P + q * PRS) + part * per;
+    for (int i = 0; i < per; ++i) prow[i] = (H)(__expf(row[i] - m) * inv);
   }
   __syncthreads();
 
@@ -214,7 +215,7 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(bf16_t* __restrict_
     for (int i = tid; i < 32 * nch; i += 256) {
       const int ch = (i & 7) | ((i >> 6) % (nch / 8)) << 3;
       const int kp = ((i >> 3) & 7) | ((i >> 6) / (nch / 8)) << 3;
-      const bf16_t* src = base + (int64_t)(k0 + 2 * kp) * 3 * C + 2 * C + ch * 8;
+      const H* src = base + (int64_t)(k0 + 2 * kp) * 3 * C + 2 * C + ch * 8;
       const uint4 lo = *reinterpret_cast<const uint4*>(src);
       const uint4 hi = *reinterpret_cast<const uint4*>(src + 3 * C);
       const unsigned short* l16 = reinterpret_cast<const unsigned short*>(&lo);
@@ -234,18 +235,18 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(bf16_t* __restrict_
         if (j < ntw) {
           const int c = (wave * ntw + j) * 16 + frow;
           const uint4 vf = *reinterpret_cast<const uint4*>(s_kv + c * VRS + (((ks * 4 + fk) ^ ((c >> 3) & 7)) << 4));
-          Mfma<bf16_t>::run(vf, pf, oacc[j]);    // rows = channels, columns = queries
+          Mfma<H>::run(vf, pf, oacc[j]);    // rows = channels, columns = queries
         }
     }
     __syncthreads();
   }
-  bf16_t* dst = out + ((int64_t)b * N + q0 + frow) * C;
+  H* dst = out + ((int64_t)b * N + q0 + frow) * C;
 #pragma unroll
   for (int j = 0; j < 4; ++j)
     if (j < ntw) {
       const int c = (wave * ntw + j) * 16 + fk * 4;
-      const bf16x4 t = {(bf16_t)oacc[j][0], (bf16_t)oacc[j][1], (bf16_t)oacc[j][2], (bf16_t)oacc[j][3]};
-      *reinterpret_cast<bf16x4*>(dst + c) = t;
+      const typename V16<H>::x4 t = {(H)oacc[j][0], (H)oacc[j][1], (H)oacc[j][2], (H)oacc[j][3]};
+      *reinterpret_cast<typename V16<H>::x4*>(dst + c) = t;
     }
 }
 
@@ -253,7 +254,8 @@ __global__ void __launch_bounds__(256) attention_mfma_kernel(bf16_t* __restrict_
 // variant: the kernel above pays one exposed memory round trip per 64-key tile (9 of them); here every load of
 // Q, K and V is requested up front (33 x 16 B per thread, 512 threads), so the 16 workgroups pay ONE round trip
 // and then only LDS phases.  8 waves: 16 keys each of a 128-key tile for the scores, 32 channels each for P.V.
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attention_mfma256_kernel(bf16_t* __restrict__ out, const bf16_t* __restrict__ qkv,
+template <typename H>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) attention_mfma256_kernel(H* __restrict__ out, const H* __restrict__ qkv,
                                                                 float scale) {
   constexpr int N = 256, C = 256;
   constexpr int KRS = C * 2 + 16;             // K-tile / Q-tile row stride (bytes)
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   const int q0 = blockIdx.x * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int frow = lane & 15, fk = lane >> 4;
-  const bf16_t* base = qkv + (int64_t)b * N * 3 * C;
+  const H* base = qkv + (int64_t)b * N * 3 * C;
   const int r32 = tid >> 5, ch = tid & 31;    // this thread's row-within-16 and 16-byte chunk for K / V items
 
   // ---- every global load of the kernel --------------------------------------------------------------------
@@ -304,7 +306,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};                                                                              \
     _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                             \
       const uint4 kf = *reinterpret_cast<const uint4*>(s_kv + (wave * 16 + frow) * KRS + (ks * 4 + fk) * 16);      \
-      Mfma<bf16_t>::run(kf, qf[ks], acc);                                                                          \
+      Mfma<H>::run(kf, qf[ks], acc);                                                                          \
     }                                                                                                              \
     *reinterpret_cast<f32x4*>(s_S + frow * N + (kt) * 128 + wave * 16 + fk * 4) = acc * scale;                     \
     __syncthreads();                                                                                               \
@@ -332,10 +334,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
     for (int off = 16; off > 0; off >>= 1) l += __shfl_xor(l, off);
     const float inv = 1.0f / l;
-    bf16x8 pv;
+    typename V16<H>::x8 pv;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) pv[i] = (bf16_t)(v[i] * inv);
-    *reinterpret_cast<bf16x8*>(s_P + q * PRS + part * 16) = pv;
+    for (int i = 0; i < 8; ++i) pv[i] = (H)(v[i] * inv);
+    *reinterpret_cast<typename V16<H>::x8*>(s_P + q * PRS + part * 16) = pv;
   }
   __syncthreads();
 
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
       _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                              \
         const int c = (wave * 2 + j) * 16 + frow;                                                                  \
         const uint4 vf = *reinterpret_cast<const uint4*>(s_kv + c * VRS + (((ks * 4 + fk) ^ ((c >> 3) & 7)) << 4)); \
-        Mfma<bf16_t>::run(vf, pf, oacc[j]);                                                                        \
+        Mfma<H>::run(vf, pf, oacc[j]);                                                                        \
       }                                                                                                            \
     }                                                                                                              \
     __syncthreads();                                                                                               \
@@ -371,12 +373,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   PV_TILE(2, vlo_4, vhi_4, vlo_5, vhi_5) PV_TILE(3, vlo_6, vhi_6, vlo_7, vhi_7)
 #undef PV_TILE
 #undef VT_ITEM
-  bf16_t* dst = out + ((int64_t)b * N + q0 + frow) * C;
+  H* dst = out + ((int64_t)b * N + q0 + frow) * C;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int c = (wave * 2 + j) * 16 + fk * 4;
-    const bf16x4 t = {(bf16_t)oacc[j][0], (bf16_t)oacc[j][1], (bf16_t)oacc[j][2], (bf16_t)oacc[j][3]};
-    *reinterpret_cast<bf16x4*>(dst + c) = t;
+    const typename V16<H>::x4 t = {(H)oacc[j][0], (H)oacc[j][1], (H)oacc[j][2], (H)oacc[j][3]};
+    *reinterpret_cast<typename V16<H>::x4*>(dst + c) = t;
   }
 }
 
@@ -388,22 +390,30 @@ extern "C" int fdbm_attention(void* out, const void* qkv, int B, int N, int C, i
   dim3 grid(cdiv(N, ATT_QB), B);
   const float scale = 1.0f / sqrtf((float)C);
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == FDBM_BF16 && N == 256 && C == 256) {
-    const size_t sm = (size_t)128 * (256 * 2 + 16) + (size_t)16 * 256 * 4 + (size_t)16 * (256 * 2 + 16);
-    static bool set256 = false;
-    if (!set256) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); set256 = true; }
-    attention_mfma256_kernel<<<dim3(N / 16, B), 512, sm, st>>>((bf16_t*)out, (const bf16_t*)qkv, scale);
-  } else if (dtype == FDBM_BF16 && N % 64 == 0 && N <= 1024 && C % 64 == 0) {
-    const int krs = C * 2 + 16;
-    const size_t kv = (size_t)(64 * krs > C * 144 ? 64 * krs : C * 144);
-    const size_t sm = kv + (size_t)16 * N * 4 + (size_t)16 * (N * 2 + 16);
-    static bool setm = false;
-    if (!setm) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); setm = true; }
-    attention_mfma_kernel<<<dim3(N / 16, B), 256, sm, st>>>((bf16_t*)out, (const bf16_t*)qkv, N, C, scale);
-  } else if (dtype == FDBM_BF16) {
-    static bool set = false;
-    if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); set = true; }
-    attention_kernel<bf16_t><<<grid, 256, smem, st>>>((bf16_t*)out, (const bf16_t*)qkv, N, C, scale);
+#define ATT_16(HT)                                                                                                       \
+  do {                                                                                                                   \
+    if (N == 256 && C == 256) {                                                                                          \
+      const size_t sm = (size_t)128 * (256 * 2 + 16) + (size_t)16 * 256 * 4 + (size_t)16 * (256 * 2 + 16);              \
+      static bool set256 = false;                                                                                        \
+      if (!set256) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma256_kernel<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024); set256 = true; } \
+      attention_mfma256_kernel<HT><<<dim3(N / 16, B), 512, sm, st>>>((HT*)out, (const HT*)qkv, scale);                   \
+    } else if (N % 64 == 0 && N <= 1024 && C % 64 == 0) {                                                                \
+      const int krs = C * 2 + 16;                                                                                        \
+      const size_t kv = (size_t)(64 * krs > C * 144 ? 64 * krs : C * 144);                                               \
+      const size_t sm = kv + (size_t)16 * N * 4 + (size_t)16 * (N * 2 + 16);                                             \
+      static bool setm = false;                                                                                          \
+      if (!setm) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_kernel<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); setm = true; } \
+      attention_mfma_kernel<HT><<<dim3(N / 16, B), 256, sm, st>>>((HT*)out, (const HT*)qkv, N, C, scale);                \
+    } else {                                                                                                             \
+      static bool set = false;                                                                                           \
+      if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<HT>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); set = true; } \
+      attention_kernel<HT><<<grid, 256, smem, st>>>((HT*)out, (const HT*)qkv, N, C, scale);                              \
+    }                                                                                                                    \
+  } while (0)
+  if (dtype == FDBM_BF16) {
+    ATT_16(bf16_t);
+  } else if (dtype == FDBM_F16) {
+    ATT_16(f16_t);
   } else if (dtype == FDBM_F32) {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); set = true; }
@@ -411,6 +421,7 @@ extern "C" int fdbm_attention(void* out, const void* qkv, int B, int N, int C, i
   } else {
     FDBM_CHECK(false, "fdbm_attention: bad dtype %d", dtype);
   }
+#undef ATT_16
   FDBM_LAUNCH_CHECK("fdbm_attention");
   return 0;
 }

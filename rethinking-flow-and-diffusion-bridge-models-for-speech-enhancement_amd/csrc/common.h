@@ -10,6 +10,13 @@
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16_t;                      // FDBM_F16 storage mode (BASELINE configs[4]); same kernels, T = f16_t
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+// vector types of a 16-bit storage type
+template <typename T> struct V16;
+template <> struct V16<bf16_t> { typedef bf16x8 x8; typedef bf16x4 x4; };
+template <> struct V16<f16_t> { typedef f16x8 x8; typedef f16x4 x4; };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -43,6 +50,10 @@ template <> struct DT<float> {
 };
 template <> struct DT<bf16_t> {
   static constexpr int code = FDBM_BF16;
+  static constexpr int vecw = 8;
+};
+template <> struct DT<f16_t> {
+  static constexpr int code = FDBM_F16;
   static constexpr int vecw = 8;
 };
 
@@ -130,17 +141,19 @@ template <> struct Vec16<float> {
     *reinterpret_cast<f32x4*>(p) = t;
   }
 };
-template <> struct Vec16<bf16_t> {
+template <typename H> struct Vec16_16 {
   static constexpr int N = 8;
-  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
-    bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+  __device__ static __forceinline__ void load(const H* p, float* v) {
+    typename V16<H>::x8 t = *reinterpret_cast<const typename V16<H>::x8*>(p);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
   }
-  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
-    bf16x8 t;
+  __device__ static __forceinline__ void store(H* p, const float* v) {
+    typename V16<H>::x8 t;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
-    *reinterpret_cast<bf16x8*>(p) = t;
+    for (int i = 0; i < 8; ++i) t[i] = (H)v[i];
+    *reinterpret_cast<typename V16<H>::x8*>(p) = t;
   }
 };
+template <> struct Vec16<bf16_t> : Vec16_16<bf16_t> {};
+template <> struct Vec16<f16_t> : Vec16_16<f16_t> {};

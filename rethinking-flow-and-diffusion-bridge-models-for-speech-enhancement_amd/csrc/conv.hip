@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256 * KG) conv_igemm_kernel(const ConvParams p
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int i = 0; i < MT; ++i) Mfma<bf16_t>::run(wf[j], af[i], acc[j][i]);
+          for (int i = 0; i < MT; ++i) Mfma<T>::run(wf[j], af[i], acc[j][i]);
       }
     } else {
       // fp32 parity mode: two-level summation.  The 32 channels of this k-step are summed in a
@@ -486,7 +486,7 @@ static int launch_conv_tile(const ConvParams& p, int bm, int bn, int kg, hipStre
   return p.gn_sums ? launch_conv_gnp<T, TO, true>(p, bm, bn, kg, st) : launch_conv_gnp<T, TO, false>(p, bm, bn, kg, st);
 }
 
-extern "C" int fdbm_conv_kc(int dtype) { return dtype == FDBM_BF16 ? 64 : 32; }
+extern "C" int fdbm_conv_kc(int dtype) { return dtype != FDBM_F32 ? 64 : 32; }
 
 // Tile / split-K plan for a conv of M pixels, Cout channels, nk k-steps (host side, also used
 // by the caller to size the split-K workspace): fills bm, bn, ksplit.
@@ -604,14 +604,14 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   FDBM_CHECK(a, "fdbm_conv_igemm: null args");
   FDBM_CHECK(a->nseg >= 1 && a->nseg <= FDBM_MAX_SEG, "fdbm_conv_igemm: nseg=%d out of range", a->nseg);
   FDBM_CHECK(a->w && a->out, "fdbm_conv_igemm: null weight/output pointer");
-  FDBM_CHECK(a->dt_in == FDBM_F32 || a->dt_in == FDBM_BF16, "fdbm_conv_igemm: bad dt_in %d", a->dt_in);
-  FDBM_CHECK(a->dt_out == FDBM_F32 || a->dt_out == FDBM_BF16, "fdbm_conv_igemm: bad dt_out %d", a->dt_out);
-  FDBM_CHECK(!(a->dt_in == FDBM_F32 && a->dt_out == FDBM_BF16), "fdbm_conv_igemm: f32 in / bf16 out is not built");
+  FDBM_CHECK(a->dt_in == FDBM_F32 || a->dt_in == FDBM_BF16 || a->dt_in == FDBM_F16, "fdbm_conv_igemm: bad dt_in %d", a->dt_in);
+  FDBM_CHECK(a->dt_out == FDBM_F32 || a->dt_out == a->dt_in, "fdbm_conv_igemm: bad dt_out %d", a->dt_out);
+  FDBM_CHECK(!(a->dt_in == FDBM_F32 && a->dt_out != FDBM_F32), "fdbm_conv_igemm: f32 in / bf16 out is not built");
   FDBM_CHECK(a->Cout > 0 && a->Cout % 4 == 0, "fdbm_conv_igemm: Cout=%d must be a positive multiple of 4", a->Cout);
   FDBM_CHECK(a->CoutPad >= a->Cout && a->CoutPad % 128 == 0, "fdbm_conv_igemm: CoutPad=%d must be a multiple of 128 >= Cout", a->CoutPad);
   FDBM_CHECK(a->B > 0 && a->H > 0 && a->W > 0, "fdbm_conv_igemm: bad shape B=%d H=%d W=%d", a->B, a->H, a->W);
   const int kc = fdbm_conv_kc(a->dt_in);
-  const int vw = a->dt_in == FDBM_BF16 ? 8 : 4;
+  const int vw = a->dt_in != FDBM_F32 ? 8 : 4;
   ConvParams p;
   memset(&p, 0, sizeof(p));
   int nk = 0;
@@ -699,7 +699,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     p.stat_out = a->stat_out; p.stat_G = a->stat_G; p.stat_nsplit = a->stat_nsplit;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (kind == 1 && (conv_policy() & 8) && a->dt_in == FDBM_BF16 && fdbm_conv_ring_ok(p)) {
+  if ((conv_policy() & 8) && (conv_policy() & 1) && a->dt_in != FDBM_F32 && fdbm_conv_ring_ok(p)) {
     // producer / consumer ring kernel: one 512-thread workgroup per CU on a 16 x 16 pixel x 128 channel tile; wants
     // (nearly) a tile per CU, below that the halo-patch kernel's 8-row tiles fill the chip better
     static const char* rmin = getenv("FDBM_RING_MIN_TILES");   // experiments
@@ -737,5 +737,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   const int kg = plan_kgroups(((M + bm - 1) / bm) * ((a->Cout + bn - 1) / bn), bm, bn, nk);
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_BF16) return launch_conv_tile<bf16_t, bf16_t>(p, bm, bn, kg, st);
   if (a->dt_in == FDBM_BF16 && a->dt_out == FDBM_F32) return launch_conv_tile<bf16_t, float>(p, bm, bn, kg, st);
+  if (a->dt_in == FDBM_F16 && a->dt_out == FDBM_F16) return launch_conv_tile<f16_t, f16_t>(p, bm, bn, kg, st);
+  if (a->dt_in == FDBM_F16 && a->dt_out == FDBM_F32) return launch_conv_tile<f16_t, float>(p, bm, bn, kg, st);
   return launch_conv_tile<float, float>(p, bm, bn, kg, st);
 }

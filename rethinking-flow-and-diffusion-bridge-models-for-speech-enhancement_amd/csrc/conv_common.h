@@ -12,6 +12,13 @@ template <> struct Mfma<bf16_t> {
                                                   *reinterpret_cast<const bf16x8*>(&b), acc, 0, 0, 0);
   }
 };
+template <> struct Mfma<f16_t> {
+  __device__ static __forceinline__ void run(const uint4& a, const uint4& b, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&a),
+                                                 *reinterpret_cast<const f16x8*>(&b), acc, 0, 0, 0);
+  }
+};
+template <> struct Mfma<float> {};        // (the f32 kernels call the 16x16x4 builtin directly)
 
 template <typename TO> struct OutVec;
 template <> struct OutVec<float> {
@@ -24,16 +31,18 @@ template <> struct OutVec<float> {
     *reinterpret_cast<f32x4*>(p) = t;
   }
 };
-template <> struct OutVec<bf16_t> {
-  __device__ static __forceinline__ void load(const bf16_t* p, float* v) {
-    bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+template <typename H> struct OutVec16 {
+  __device__ static __forceinline__ void load(const H* p, float* v) {
+    typename V16<H>::x4 t = *reinterpret_cast<const typename V16<H>::x4*>(p);
     v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
   }
-  __device__ static __forceinline__ void store(bf16_t* p, const float* v) {
-    bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-    *reinterpret_cast<bf16x4*>(p) = t;
+  __device__ static __forceinline__ void store(H* p, const float* v) {
+    typename V16<H>::x4 t = {(H)v[0], (H)v[1], (H)v[2], (H)v[3]};
+    *reinterpret_cast<typename V16<H>::x4*>(p) = t;
   }
 };
+template <> struct OutVec<bf16_t> : OutVec16<bf16_t> {};
+template <> struct OutVec<f16_t> : OutVec16<f16_t> {};
 
 struct ConvParams {
   fdbm_conv_seg seg[FDBM_MAX_SEG];
@@ -148,7 +157,7 @@ __device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int64_t m, i
   OutVec<TO>::store(reinterpret_cast<TO*>(p.out) + m * Cout + n, v);
   if constexpr (sizeof(TO) == 2) {     // statistics are those of the STORED tensor
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (float)(bf16_t)v[r];
+    for (int r = 0; r < 4; ++r) v[r] = (float)(TO)v[r];
   }
 }
 
@@ -265,7 +274,7 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
 template <typename T>
 __device__ __forceinline__ uint4 gn_transform16(uint4 v, const float* tsc, const float* tsh, bool silu) {
   if constexpr (sizeof(T) == 2) {
-    bf16x8 e = *reinterpret_cast<bf16x8*>(&v);
+    typename V16<T>::x8 e = *reinterpret_cast<typename V16<T>::x8*>(&v);
     float y[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) y[q] = (float)e[q] * tsc[q] + tsh[q];
@@ -274,7 +283,7 @@ __device__ __forceinline__ uint4 gn_transform16(uint4 v, const float* tsc, const
       for (int q = 0; q < 8; ++q) y[q] = silu_f(y[q]);
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) e[q] = (bf16_t)y[q];
+    for (int q = 0; q < 8; ++q) e[q] = (T)y[q];
     return *reinterpret_cast<uint4*>(&e);
   } else {
     f32x4 e = *reinterpret_cast<f32x4*>(&v);

@@ -196,7 +196,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int i = 0; i < MT; ++i) Mfma<bf16_t>::run(wf[j], af[i], acc[j][i]);
+          for (int i = 0; i < MT; ++i) Mfma<T>::run(wf[j], af[i], acc[j][i]);
         __builtin_amdgcn_s_setprio(0);
       } else {
 #pragma unroll
@@ -362,5 +362,7 @@ static int launch_patch_th(const ConvParams& p, int th, hipStream_t st) {
 int fdbm_launch_conv_patch(const ConvParams& p, int dt_in, int dt_out, int th, hipStream_t st) {
   if (dt_in == FDBM_BF16 && dt_out == FDBM_BF16) return launch_patch_th<bf16_t, bf16_t>(p, th, st);
   if (dt_in == FDBM_BF16 && dt_out == FDBM_F32) return launch_patch_th<bf16_t, float>(p, th, st);
+  if (dt_in == FDBM_F16 && dt_out == FDBM_F16) return launch_patch_th<f16_t, f16_t>(p, th, st);
+  if (dt_in == FDBM_F16 && dt_out == FDBM_F32) return launch_patch_th<f16_t, float>(p, th, st);
   return launch_patch_th<float, float>(p, th, st);
 }

@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
               } else {
                 ta = uint2{rw[i][q].x, rw[i][q].y}; tb = uint2{rw[i][q].z, rw[i][q].w};
               }
-              const bf16x4 ea = *reinterpret_cast<const bf16x4*>(&ta), eb = *reinterpret_cast<const bf16x4*>(&tb);
+              const typename V16<TO>::x4 ea = *reinterpret_cast<const typename V16<TO>::x4*>(&ta), eb = *reinterpret_cast<const typename V16<TO>::x4*>(&tb);
 #pragma unroll
               for (int r = 0; r < 4; ++r) { r0[r] = (float)ea[r]; r1[r] = (float)eb[r]; }
             } else {
@@ -689,7 +689,7 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
               v[r] *= scale;
             }
             if constexpr (WIDE) {
-              bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+              typename V16<TO>::x4 t = {(TO)v[0], (TO)v[1], (TO)v[2], (TO)v[3]};
               pk[j] = *reinterpret_cast<uint2*>(&t);
 #pragma unroll
               for (int r = 0; r < 4; ++r) v[r] = (float)t[r];            // statistics are those of the STORED tensor
@@ -790,6 +790,10 @@ int fdbm_launch_conv_ring(const ConvParams& p, int dt_in, int dt_out, hipStream_
     return gnp ? launch_ring<bf16_t, bf16_t, true>(p, st) : launch_ring<bf16_t, bf16_t, false>(p, st);
   if (dt_in == FDBM_BF16 && dt_out == FDBM_F32)
     return gnp ? launch_ring<bf16_t, float, true>(p, st) : launch_ring<bf16_t, float, false>(p, st);
+  if (dt_in == FDBM_F16 && dt_out == FDBM_F16)
+    return gnp ? launch_ring<f16_t, f16_t, true>(p, st) : launch_ring<f16_t, f16_t, false>(p, st);
+  if (dt_in == FDBM_F16 && dt_out == FDBM_F32)
+    return gnp ? launch_ring<f16_t, float, true>(p, st) : launch_ring<f16_t, float, false>(p, st);
   fdbm_set_error("fdbm_conv_igemm(ring): unsupported dtypes %d -> %d", dt_in, dt_out);
   return 1;
 }

@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
 
   auto mma = [&](const uint4& wf, const uint4& af, f32x4& c) __attribute__((always_inline)) {
     if constexpr (!F32) {
-      Mfma<bf16_t>::run(wf, af, c);
+      Mfma<T>::run(wf, af, c);
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -573,5 +573,7 @@ static int launch_tap_shape(const ConvParams& p, int tw, int nt, hipStream_t st)
 int fdbm_launch_conv_tap(const ConvParams& p, int dt_in, int dt_out, int tw, int nt, hipStream_t st) {
   if (dt_in == FDBM_BF16 && dt_out == FDBM_BF16) return launch_tap_shape<bf16_t, bf16_t>(p, tw, nt, st);
   if (dt_in == FDBM_BF16 && dt_out == FDBM_F32) return launch_tap_shape<bf16_t, float>(p, tw, nt, st);
+  if (dt_in == FDBM_F16 && dt_out == FDBM_F16) return launch_tap_shape<f16_t, f16_t>(p, tw, nt, st);
+  if (dt_in == FDBM_F16 && dt_out == FDBM_F32) return launch_tap_shape<f16_t, float>(p, tw, nt, st);
   return launch_tap_shape<float, float>(p, tw, nt, st);
 }

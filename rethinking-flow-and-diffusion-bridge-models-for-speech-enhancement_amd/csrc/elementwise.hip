@@ -145,6 +145,72 @@ extern "C" int fdbm_pc_corrector(void* x_new, void* x_mean, const void* x, const
   return 0;
 }
 
+// Langevin corrector step size ON THE DEVICE (fdbm/util/correctors.py:46-51): grad_norm = mean_b ||score_b||,
+// noise_norm = mean_b ||noise_b||, step = (snr * noise_norm / (grad_norm + 1e-8))^2 * 2 for every sample,
+// noise_scale = sqrt(step * 2).  The host version fetched two norms per step (a device synchronisation inside the
+// sampler loop, and nothing a HIP graph can capture); here two launches leave step[B] / noise_scale[B] where
+// fdbm_pc_corrector reads them.  Norms in fp64 partial sums (the reference: fp32 torch.norm).
+__global__ void __launch_bounds__(256) langevin_norm_kernel(double* __restrict__ part, const float* __restrict__ x,
+                                                            const float* __restrict__ s, const float* __restrict__ y,
+                                                            const float* __restrict__ nz, const float* a, const float* b,
+                                                            const float* den, int64_t nfloat) {
+  __shared__ double red[2][256];
+  const int bi = blockIdx.y;
+  const float fa = a[bi], fb = b[bi], fd = den[bi];
+  const int64_t base = (int64_t)bi * nfloat;
+  double g2 = 0.0, n2 = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nfloat; i += (int64_t)gridDim.x * blockDim.x) {
+    const float mean = __fadd_rn(__fmul_rn(fa, s[base + i]), __fmul_rn(fb, y[base + i]));
+    const float score = __fdiv_rn(-__fsub_rn(x[base + i], mean), fd);
+    const float z = nz[base + i];
+    g2 += (double)score * (double)score;
+    n2 += (double)z * (double)z;
+  }
+  red[0][threadIdx.x] = g2; red[1][threadIdx.x] = n2;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) { red[0][threadIdx.x] += red[0][threadIdx.x + st]; red[1][threadIdx.x] += red[1][threadIdx.x + st]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    part[((int64_t)bi * gridDim.x + blockIdx.x) * 2] = red[0][0];
+    part[((int64_t)bi * gridDim.x + blockIdx.x) * 2 + 1] = red[1][0];
+  }
+}
+
+__global__ void __launch_bounds__(64) langevin_step_kernel(float* __restrict__ step, float* __restrict__ nscale,
+                                                           const double* __restrict__ part, int B, int gx, float snr) {
+  // one wave: lane l sums samples l, l + 64, ...
+  double gsum = 0.0, nsum = 0.0;
+  for (int bi = threadIdx.x; bi < B; bi += 64) {
+    double g2 = 0.0, n2 = 0.0;
+    for (int k = 0; k < gx; ++k) { g2 += part[((int64_t)bi * gx + k) * 2]; n2 += part[((int64_t)bi * gx + k) * 2 + 1]; }
+    gsum += (double)(float)sqrt(g2);          // per-sample norms are fp32 tensors in the reference
+    nsum += (double)(float)sqrt(n2);
+  }
+  for (int o = 32; o > 0; o >>= 1) { gsum += __shfl_xor(gsum, o, 64); nsum += __shfl_xor(nsum, o, 64); }
+  const float gmean = (float)(gsum / (double)B), nmean = (float)(nsum / (double)B);
+  const float r = __fdiv_rn(__fmul_rn(snr, nmean), __fadd_rn(gmean, 1e-8f));
+  const float st = __fmul_rn(__fmul_rn(r, r), 2.0f);
+  const float ns = sqrtf(__fmul_rn(st, 2.0f));
+  for (int bi = threadIdx.x; bi < B; bi += 64) { step[bi] = st; nscale[bi] = ns; }
+}
+
+extern "C" int fdbm_langevin_step(float* step, float* noise_scale, void* scratch, const void* x, const void* s,
+                                  const void* y, const void* noise, const float* a, const float* b, const float* den,
+                                  float snr, int B, int64_t n_complex, void* stream) {
+  FDBM_CHECK(step && noise_scale && scratch && x && s && y && noise && a && b && den, "fdbm_langevin_step: null pointer");
+  FDBM_CHECK(B > 0 && n_complex > 0, "fdbm_langevin_step: bad shape");
+  const int64_t nfloat = n_complex * 2;
+  const int gx = 64;                        // scratch: B * 64 * 2 doubles
+  langevin_norm_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>((double*)scratch, (const float*)x, (const float*)s,
+                                                                   (const float*)y, (const float*)noise, a, b, den, nfloat);
+  FDBM_LAUNCH_CHECK("fdbm_langevin_step/norms");
+  langevin_step_kernel<<<1, 64, 0, (hipStream_t)stream>>>(step, noise_scale, (const double*)scratch, B, gx, snr);
+  FDBM_LAUNCH_CHECK("fdbm_langevin_step/step");
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------
 // network input / output
 // ---------------------------------------------------------------------------------
@@ -247,7 +313,7 @@ extern "C" int fdbm_combine(void* out, const void* h, const float* pyr, const fl
                             const float* bias, int64_t M, int C, int dtype, void* stream) {
   FDBM_CHECK(out && h && pyr && w && bias, "fdbm_combine: null pointer");
   FDBM_CHECK(C % 8 == 0, "fdbm_combine: C=%d must be a multiple of 8", C);
-  const int vw = dtype == FDBM_BF16 ? 8 : 4;
+  const int vw = dtype != FDBM_F32 ? 8 : 4;
   const int64_t total = M * (C / vw);
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
@@ -256,6 +322,9 @@ extern "C" int fdbm_combine(void* out, const void* h, const float* pyr, const fl
   if (dtype == FDBM_BF16)
     combine_kernel<bf16_t><<<g, 256, 0, st>>>((bf16_t*)out, (const bf16_t*)h, (const f32x4*)pyr,
                                               (const f32x4*)w, bias, M, C);
+  else if (dtype == FDBM_F16)
+    combine_kernel<f16_t><<<g, 256, 0, st>>>((f16_t*)out, (const f16_t*)h, (const f32x4*)pyr,
+                                             (const f32x4*)w, bias, M, C);
   else if (dtype == FDBM_F32)
     combine_kernel<float><<<g, 256, 0, st>>>((float*)out, (const float*)h, (const f32x4*)pyr,
                                              (const f32x4*)w, bias, M, C);
@@ -413,7 +482,7 @@ __global__ void __launch_bounds__(256) conv_stem_kernel(T* __restrict__ out,
   if constexpr (sizeof(T) == 2) {
     Vec16<T>::store(dst, o);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (float)(bf16_t)o[j];       // statistics of the STORED tensor
+    for (int j = 0; j < 8; ++j) o[j] = (float)(T)o[j];       // statistics of the STORED tensor
   } else {
     Vec16<T>::store(dst, o);
     Vec16<T>::store(dst + 4, o + 4);
@@ -498,7 +567,7 @@ __global__ void __launch_bounds__(256) conv_stem_mfma_kernel(T* __restrict__ out
       OutVec<T>::store(dst + j * 16, o);
       if constexpr (sizeof(T) == 2) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (float)(bf16_t)o[r];       // statistics of the STORED tensor
+        for (int r = 0; r < 4; ++r) o[r] = (float)(T)o[r];       // statistics of the STORED tensor
       }
       u1[j] += (o[0] + o[1]) + (o[2] + o[3]);
       u2[j] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
@@ -539,6 +608,7 @@ extern "C" int fdbm_conv_stem_stats(void* out, const float* in, const float* w, 
 #define STEM_MFMA(TT, NTT) conv_stem_mfma_kernel<TT, NTT><<<grid, 256, 0, st>>>((TT*)out, in, w, bias, H, W, stat_out, stat_nsplit, tpw)
 #define STEM_NT(TT) do { if (nf == 128) STEM_MFMA(TT, 8); else if (nf == 96) STEM_MFMA(TT, 6); else if (nf == 64) STEM_MFMA(TT, 4); else STEM_MFMA(TT, 2); } while (0)
     if (dt_out == FDBM_BF16) STEM_NT(bf16_t);
+    else if (dt_out == FDBM_F16) STEM_NT(f16_t);
     else if (dt_out == FDBM_F32) STEM_NT(float);
     else FDBM_CHECK(false, "fdbm_conv_stem: bad dtype %d", dt_out);
 #undef STEM_NT
@@ -558,6 +628,8 @@ extern "C" int fdbm_conv_stem_stats(void* out, const float* in, const float* w, 
   dim3 grid(gs, B);
   if (dt_out == FDBM_BF16)
     conv_stem_kernel<bf16_t><<<grid, 256, smem, st>>>((bf16_t*)out, (const f32x4*)in, w, bias, H, W, nf, stat_out, stat_nsplit);
+  else if (dt_out == FDBM_F16)
+    conv_stem_kernel<f16_t><<<grid, 256, smem, st>>>((f16_t*)out, (const f32x4*)in, w, bias, H, W, nf, stat_out, stat_nsplit);
   else if (dt_out == FDBM_F32)
     conv_stem_kernel<float><<<grid, 256, smem, st>>>((float*)out, (const f32x4*)in, w, bias, H, W, nf, stat_out, stat_nsplit);
   else

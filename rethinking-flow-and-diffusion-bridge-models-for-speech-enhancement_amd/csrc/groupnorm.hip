@@ -89,7 +89,7 @@ extern "C" int fdbm_gn_stats(float* partial, const void* src0, int C0, const voi
                              int B, int HW, int G, int nsplit, int dtype, void* stream) {
   FDBM_CHECK(partial && src0, "fdbm_gn_stats: null pointer");
   FDBM_CHECK((src1 != nullptr) == (C1 > 0), "fdbm_gn_stats: src1/C1 mismatch");
-  const int vw = dtype == FDBM_BF16 ? 8 : 4;
+  const int vw = dtype != FDBM_F32 ? 8 : 4;
   FDBM_CHECK(C0 % vw == 0 && C1 % vw == 0, "fdbm_gn_stats: channels (%d,%d) must be multiples of %d", C0, C1, vw);
   FDBM_CHECK(C0 / vw <= 256 && C1 / vw <= 256 && C0 + C1 <= GN_MAXC, "fdbm_gn_stats: too many channels");
   FDBM_CHECK(G > 0 && G <= 32 && (C0 + C1) % G == 0, "fdbm_gn_stats: C=%d not divisible by G=%d (G <= 32)", C0 + C1, G);
@@ -98,6 +98,8 @@ extern "C" int fdbm_gn_stats(float* partial, const void* src0, int C0, const voi
   hipStream_t st = (hipStream_t)stream;
   if (dtype == FDBM_BF16)
     gn_stats_kernel<bf16_t, float><<<grid, 256, 0, st>>>(partial, (const bf16_t*)src0, C0, (const bf16_t*)src1, C1, HW, G, nsplit);
+  else if (dtype == FDBM_F16)
+    gn_stats_kernel<f16_t, float><<<grid, 256, 0, st>>>(partial, (const f16_t*)src0, C0, (const f16_t*)src1, C1, HW, G, nsplit);
   else if (dtype == FDBM_F32)   // fp64 partials: `partial` must hold B*nsplit*G*2 doubles; consumers get nsplit negated
     gn_stats_kernel<float, double><<<grid, 256, 0, st>>>((double*)partial, (const float*)src0, C0, (const float*)src1, C1, HW, G, nsplit);
   else
@@ -184,7 +186,7 @@ extern "C" int fdbm_gn_apply(void* out, const void* src0, int C0, const void* sr
                              int dtype, void* stream) {
   FDBM_CHECK(out && src0 && stats && gamma && beta, "fdbm_gn_apply: null pointer");
   FDBM_CHECK((src1 != nullptr) == (C1 > 0), "fdbm_gn_apply: src1/C1 mismatch");
-  const int vw = dtype == FDBM_BF16 ? 8 : 4;
+  const int vw = dtype != FDBM_F32 ? 8 : 4;
   const int C = C0 + C1;
   FDBM_CHECK(C0 % vw == 0 && C1 % vw == 0 && C <= GN_MAXC && G > 0 && G <= 32 && C % G == 0,
              "fdbm_gn_apply: bad channels (%d,%d) G=%d", C0, C1, G);
@@ -198,6 +200,7 @@ extern "C" int fdbm_gn_apply(void* out, const void* src0, int C0, const void* sr
   const double inv = nsplit != 0 ? 1.0 / (double)count : 0.0;
 #define GN_APPLY(TT, S) gn_apply_kernel<TT, S><<<grid, 256, 0, st>>>((TT*)out, (const TT*)src0, C0, (const TT*)src1, C1, stats, nsplit, inv, eps, gamma, beta, HW, G, chunks)
   if (dtype == FDBM_BF16) { if (silu) GN_APPLY(bf16_t, true); else GN_APPLY(bf16_t, false); }
+  else if (dtype == FDBM_F16) { if (silu) GN_APPLY(f16_t, true); else GN_APPLY(f16_t, false); }
   else if (dtype == FDBM_F32) { if (silu) GN_APPLY(float, true); else GN_APPLY(float, false); }
   else FDBM_CHECK(false, "fdbm_gn_apply: bad dtype %d", dtype);
 #undef GN_APPLY

@@ -305,7 +305,7 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
   FDBM_CHECK(!out_act || (gamma && beta && G > 0 && G <= 32 && C % G == 0 && C <= 1024), "fdbm_resample2x: bad GroupNorm arguments");
   FDBM_CHECK(nsplit == 0 || count > 0, "fdbm_resample2x: bad nsplit/count");
   const double inv_count = nsplit != 0 ? 1.0 / (double)count : 0.0;
-  const int vw = dtype == FDBM_BF16 ? 8 : 4;
+  const int vw = dtype != FDBM_F32 ? 8 : 4;
   FDBM_CHECK(C % vw == 0, "fdbm_resample2x: C=%d must be a multiple of %d", C, vw);
   FDBM_CHECK(up || (H % 2 == 0 && W % 2 == 0), "fdbm_resample2x: downsampling needs even H, W (got %d x %d)", H, W);
   hipStream_t st = (hipStream_t)stream;
@@ -343,6 +343,7 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
   } while (0)
     if (smem <= 64 * 1024) {
       if (dtype == FDBM_BF16) RT_DISPATCH(bf16_t);
+      else if (dtype == FDBM_F16) RT_DISPATCH(f16_t);
       else if (dtype == FDBM_F32) RT_DISPATCH(float);
       else FDBM_CHECK(false, "fdbm_resample2x: bad dtype %d", dtype);
       FDBM_LAUNCH_CHECK("fdbm_resample2x(tile)");
@@ -369,6 +370,7 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
     else    { if (P_ && A_) RS(TT, false, true, true); else if (P_) RS(TT, false, true, false); else RS(TT, false, false, true); } \
   } while (0)
   if (dtype == FDBM_BF16) RS_DISPATCH(bf16_t);
+  else if (dtype == FDBM_F16) RS_DISPATCH(f16_t);
   else if (dtype == FDBM_F32) RS_DISPATCH(float);
   else FDBM_CHECK(false, "fdbm_resample2x: bad dtype %d", dtype);
 #undef RS_DISPATCH

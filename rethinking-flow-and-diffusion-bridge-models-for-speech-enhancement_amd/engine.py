@@ -73,6 +73,107 @@ class SamplerGraph:
         return prog.x_in.clone()
 
 
+class PcGraph:
+    """Predictor-corrector sampler (fdbm/bridge.py:142-166 with EulerMaruyamaPredictor, fdbm/util/predictors.py:40-51,
+    and AnnealedLangevinDynamics / LangevinCorrector / none, fdbm/util/correctors.py:37-81) as ONE HIP graph: per grid
+    point {corrector_steps x [backbone ; corrector move] ; backbone ; predictor move}.  Every scalar of ald / the
+    predictor is a host table uploaded once; the Langevin corrector's norm-ratio step size is computed by
+    fdbm_langevin_step on the device.  Noise of all steps is drawn on the host in the reference's call order and
+    uploaded before the replay."""
+
+    def __init__(self, net, bridge, B, F, T, predictor_name, corrector_name, snr, n_steps):
+        from .paths import ProbabilityPathSB  # noqa: F401  (sde_weights lives on the path)
+        self.net, self.N, self.B = net, bridge.N, B
+        self.pred, self.corr, self.snr = predictor_name, corrector_name, float(snr)
+        self.n_steps = n_steps if corrector_name != "none" else 0
+        self.prog = net.program(B, F, T)
+        dev = net.device
+        ts = bridge.time_grid(self.N)
+        path = bridge.path
+        ctab, ptab, dts = [], [], []
+        for i in range(self.N):
+            vt = torch.ones(B) * ts[i]
+            a_t, b_t, sig = path.path_param(vt)
+            den = sig ** 2 + 1e-8
+            std = bridge._std(vt)
+            step = (self.snr * std) ** 2 * 2
+            ctab.append(torch.stack([a_t, b_t, den, step, torch.sqrt(step * 2)]).to(torch.float32))
+            ptab.append(torch.stack([w.to(torch.float32) for w in path.sde_weights(vt)]))
+            stepsize = ts[i] - ts[i + 1] if i != self.N - 1 else ts[-1]
+            dts.append(-float(stepsize))
+        self.ctab = torch.stack(ctab).to(dev).contiguous()         # [N,5,B]
+        self.ptab = torch.stack(ptab).to(dev).contiguous()         # [N,4,B]
+        self.dts = dts
+        self.t_tab = torch.log(ts[:, None] * torch.ones(1, B)).to(dev).contiguous()
+        z = lambda *lead: torch.zeros(*lead, B, 1, F, T, dtype=torch.complex64, device=dev)
+        self.zc = z(self.N, max(self.n_steps, 1))
+        self.zp = z(self.N)
+        self.x_new, self.x_mean = z(), z()
+        self.lstep = torch.zeros(2, B, device=dev)
+        self.lscratch = torch.zeros(B * 128, dtype=torch.float64, device=dev)
+        self.graph = None
+        self.key = SamplerGraph._bridge_key(bridge)
+
+    def _steps(self):
+        prog, B = self.prog, self.B
+        n = prog.x_in[0].numel()
+        p = hip.ptr
+        for i in range(self.N):
+            for k in range(self.n_steps):
+                hip.call("fdbm_copy_f32", p(prog.t_in), p(self.t_tab[i]), B)
+                prog.run()
+                c = self.ctab[i]
+                step, nscale = c[3], c[4]
+                if self.corr == "langevin":
+                    hip.call("fdbm_langevin_step", p(self.lstep[0]), p(self.lstep[1]), p(self.lscratch), p(prog.x_in),
+                             p(prog.s_out), p(prog.y_in), p(self.zc[i, k]), p(c[0]), p(c[1]), p(c[2]), self.snr, B, n)
+                    step, nscale = self.lstep[0], self.lstep[1]
+                hip.call("fdbm_pc_corrector", p(self.x_new), p(self.x_mean), p(prog.x_in), p(prog.s_out), p(prog.y_in),
+                         p(self.zc[i, k]), p(c[0]), p(c[1]), p(c[2]), p(step), p(nscale), B, n)
+                hip.call("fdbm_copy_f32", p(prog.x_in), p(self.x_new), 2 * B * n)
+            if self.pred == "euler_maruyama":
+                hip.call("fdbm_copy_f32", p(prog.t_in), p(self.t_tab[i]), B)
+                prog.run()
+                w = self.ptab[i]
+                hip.call("fdbm_pc_predictor", p(self.x_new), p(self.x_mean), p(prog.x_in), p(prog.s_out), p(prog.y_in),
+                         p(self.zp[i]), p(w[0]), p(w[1]), p(w[2]), p(w[3]), self.dts[i], B, n)
+                hip.call("fdbm_copy_f32", p(prog.x_in), p(self.x_new), 2 * B * n)
+            else:
+                hip.call("fdbm_copy_f32", p(self.x_mean), p(prog.x_in), 2 * B * n)      # NonePredictor returns (x, x): x_mean = x
+
+    capture = SamplerGraph.capture
+
+    def run(self, y, x0, noise, denoise):
+        prog = self.prog
+        # the reference draws: per grid point the corrector's noise (after its model call), then the predictor's (before
+        # its model call) - the generator only sees the ORDER of the draws
+        for i in range(self.N):
+            for k in range(self.n_steps):
+                self.zc[i, k].copy_(noise.step())
+            if self.pred == "euler_maruyama":
+                self.zp[i].copy_(noise.step())
+        prog.y_in.copy_(y)
+        prog.x_in.copy_(x0)
+        if self.graph is None:
+            self.capture()
+            prog.y_in.copy_(y)
+            prog.x_in.copy_(x0)
+        self.graph.replay()
+        return (self.x_mean if denoise else prog.x_in).clone()
+
+
+def pc_with_graph(net, bridge, y, noise, predictor_name, corrector_name, snr, n_steps, denoise):
+    """Fast path of Bridge.pc_sampler for this package's backbone and the registered predictors / correctors."""
+    B, _, F, T = y.shape
+    key = ("pc", B, F, T, predictor_name, corrector_name, float(snr), int(n_steps), SamplerGraph._bridge_key(bridge))
+    pg = net._graphs.get(key)
+    if pg is None:
+        pg = net._graphs[key] = PcGraph(net, bridge, B, F, T, predictor_name, corrector_name, snr, n_steps)
+    with torch.no_grad():
+        x0 = bridge.prior_sampling(y.contiguous(), noise)
+        return pg.run(y.contiguous(), x0, noise, denoise)
+
+
 def sample_with_graph(net, bridge, y, kind, noise):
     """Fast path of Bridge.ode_sampler_ei / sde_sampler_ei for this package's backbone."""
     B, _, F, T = y.shape

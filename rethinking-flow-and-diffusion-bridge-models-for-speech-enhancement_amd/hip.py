@@ -13,7 +13,7 @@ import torch
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.environ.get("FDBM_HIP_LIB") or os.path.join(_CSRC, "libfdbm_hip.so")   # env: diagnostic builds
 
-F32, BF16 = 0, 1
+F32, BF16, F16 = 0, 1, 2
 MAX_SEG = 4
 _lib = None
 
@@ -58,6 +58,7 @@ _SIGS = {
     "fdbm_bridge_update": [c_void_p] * 7 + [c_int, c_i64],
     "fdbm_pc_predictor": [c_void_p] * 10 + [c_float, c_int, c_i64],
     "fdbm_pc_corrector": [c_void_p] * 11 + [c_int, c_i64],
+    "fdbm_langevin_step": [c_void_p] * 10 + [c_float, c_int, c_i64],
     "fdbm_pack_input": [c_void_p] * 3 + [c_int] * 4,
     "fdbm_unpack_output": [c_void_p] * 4 + [c_int] * 4,
     "fdbm_temb": [c_void_p] * 8 + [c_int] * 2,
@@ -148,6 +149,8 @@ def dt_code(dtype):
         return F32
     if dtype == torch.bfloat16:
         return BF16
+    if dtype == torch.float16:
+        return F16
     raise ValueError(f"unsupported activation dtype {dtype}")
 
 
@@ -214,6 +217,19 @@ def pc_corrector(x, s, y, noise, a, b, den, step, nscale):
     call("fdbm_pc_corrector", ptr(x_new), ptr(x_mean), *[ptr(v) for v in ts_], *[ptr(w) for w in ws_],
          x.shape[0], x[0].numel())
     return x_new, x_mean
+
+
+def langevin_step(x, s, y, noise, a, b, den, snr):
+    """-> (step [B], noise_scale [B]) device float32 tensors (fdbm_langevin_step: no host round trip)."""
+    dev = x.device
+    B = x.shape[0]
+    step, nscale = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    scratch = torch.empty(B * 128, dtype=torch.float64, device=dev)
+    ws_ = [_dev_f32(w, dev) for w in (a, b, den)]
+    ts_ = [v.contiguous() for v in (x, s, y, noise)]
+    call("fdbm_langevin_step", ptr(step), ptr(nscale), ptr(scratch), *[ptr(v) for v in ts_], *[ptr(w) for w in ws_],
+         float(snr), B, x[0].numel())
+    return step, nscale
 
 
 def upfirdn2d(inp, kernel, up=1, down=1, pad=(0, 0)):

@@ -170,7 +170,7 @@ class Program:
         self.dev = net.device
         self.dt = net.dtype
         self.dtc = hip.dt_code(net.dtype)
-        self.esize = 2 if net.dtype == torch.bfloat16 else 4
+        self.esize = 4 if net.dtype == torch.float32 else 2
         self.pool = Pool(self.dev)
         self.ops = []          # (opcode, iargs, fargs, lane)
         self.keep = []         # tensors that must outlive the program
@@ -197,7 +197,7 @@ class Program:
     # ---- buffers ---------------------------------------------------------------------
     def new_act(self, H, W, C, dtype=None):
         dtype = dtype or self.dt
-        es = 2 if dtype == torch.bfloat16 else 4
+        es = 4 if dtype == torch.float32 else 2
         raw = self.pool.get(self.B * H * W * C * es)
         return Act(raw, self.B, H, W, C, dtype)
 

@@ -364,6 +364,31 @@ void fdbm_ncsnpp_destroy(fdbm_ncsnpp_ctx* ctx);
 int fdbm_ncsnpp_forward(fdbm_ncsnpp_ctx* ctx, const void* x, const void* y, const float* log_t,
                         void* out, void* stream);
 
+/* ------------------------------------------------------------------ contexts without Python
+ * The architecture walk of NCSNpp_v2 (fdbm/backbones/ncsnpp_v2.py:95-401) is recorded once per (variant, B, F, T,
+ * dtype) and SERIALISED (python -m tools.export_program, fdbm_amd/export.py): a "program" (this header, the fdbm_op
+ * array, the fdbm_conv_args table; every pointer stored as region + offset) and a flat weight blob in the kernels'
+ * device formats.  A host in any language then needs: the two files, ONE device buffer for the weights (upload the
+ * blob), ONE caller-owned workspace of fdbm_program_workspace_bytes() bytes, and
+ *     ctx = fdbm_ncsnpp_create_from_program(program, n, weights_dev, workspace_dev, workspace_bytes);
+ *     fdbm_ncsnpp_forward(ctx, x, y, log_t, out, stream);       // never allocates, never synchronises
+ * (examples/host_cpp/run_program.cpp is such a host).  Pointers inside the program: bit 62 set, bits 60-61 = region
+ * (0 workspace, 1 weights), low bits = byte offset. */
+typedef struct fdbm_program_header {
+  uint64_t magic;                 /* 0x474F5250424D4446 */
+  uint32_t version, n_ops, n_conv, conv_args_size;
+  int64_t workspace_bytes, weights_bytes;
+  int32_t B, F, T, dtype;
+  int64_t x_in, y_in, t_in, s_out;    /* relocatable pointers of the static I/O buffers */
+  int64_t n_complex;
+  uint8_t reserved[32];
+} fdbm_program_header;             /* 128 bytes, followed by fdbm_op[n_ops], fdbm_conv_args[n_conv] */
+int64_t fdbm_program_workspace_bytes(const void* program, int64_t nbytes);    /* < 0: not a program */
+int64_t fdbm_program_weights_bytes(const void* program, int64_t nbytes);
+/* the workspace is zeroed here (synchronously: context creation is not on the hot path) */
+fdbm_ncsnpp_ctx* fdbm_ncsnpp_create_from_program(const void* program, int64_t nbytes, void* weights_dev,
+                                                 void* workspace_dev, int64_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif

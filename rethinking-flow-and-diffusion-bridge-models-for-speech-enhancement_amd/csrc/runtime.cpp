@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -174,6 +176,7 @@ extern "C" int fdbm_run_program(const fdbm_op* ops, int n_ops, void* main_stream
 // composed backbone entry: a context = a recorded program + its static I/O buffers
 // ---------------------------------------------------------------------------------
 struct fdbm_ncsnpp_ctx {
+  fdbm_conv_args* convs = nullptr;   // owned copies (contexts created from a serialised program)
   fdbm_op* ops;
   int n_ops;
   void* x_in;
@@ -201,7 +204,92 @@ extern "C" fdbm_ncsnpp_ctx* fdbm_ncsnpp_create(const fdbm_op* ops_host, int n_op
 extern "C" void fdbm_ncsnpp_destroy(fdbm_ncsnpp_ctx* c) {
   if (!c) return;
   delete[] c->ops;
+  delete[] c->convs;
   delete c;
+}
+
+// ---- serialised programs (include/fdbm_hip.h "contexts without Python", fdbm_amd/export.py) --------------------
+static const fdbm_program_header* program_header(const void* program, int64_t nbytes) {
+  if (!program || nbytes < (int64_t)sizeof(fdbm_program_header)) { fdbm_set_error("program: too short"); return nullptr; }
+  const fdbm_program_header* h = reinterpret_cast<const fdbm_program_header*>(program);
+  if (h->magic != 0x474F5250424D4446ull || h->version != 1) { fdbm_set_error("program: bad magic / version"); return nullptr; }
+  if (h->conv_args_size != sizeof(fdbm_conv_args)) {
+    fdbm_set_error("program: fdbm_conv_args is %u bytes in the file, %zu in this library", h->conv_args_size, sizeof(fdbm_conv_args));
+    return nullptr;
+  }
+  const int64_t need = (int64_t)sizeof(fdbm_program_header) + (int64_t)h->n_ops * (int64_t)sizeof(fdbm_op) +
+                       (int64_t)h->n_conv * (int64_t)sizeof(fdbm_conv_args);
+  if (nbytes < need) { fdbm_set_error("program: %lld bytes, %lld needed", (long long)nbytes, (long long)need); return nullptr; }
+  return h;
+}
+extern "C" int64_t fdbm_program_workspace_bytes(const void* program, int64_t nbytes) {
+  const fdbm_program_header* h = program_header(program, nbytes);
+  return h ? h->workspace_bytes : -1;
+}
+extern "C" int64_t fdbm_program_weights_bytes(const void* program, int64_t nbytes) {
+  const fdbm_program_header* h = program_header(program, nbytes);
+  return h ? h->weights_bytes : -1;
+}
+
+extern "C" fdbm_ncsnpp_ctx* fdbm_ncsnpp_create_from_program(const void* program, int64_t nbytes, void* weights_dev,
+                                                            void* workspace_dev, int64_t workspace_bytes) {
+  const fdbm_program_header* h = program_header(program, nbytes);
+  if (!h) return nullptr;
+  if (!weights_dev || !workspace_dev || workspace_bytes < h->workspace_bytes) {
+    fdbm_set_error("fdbm_ncsnpp_create_from_program: workspace of %lld bytes, %lld needed", (long long)workspace_bytes,
+                   (long long)h->workspace_bytes);
+    return nullptr;
+  }
+  bool bad = false;
+  auto reloc = [&](int64_t v) -> void* {
+    if (v == 0) return nullptr;
+    if (((uint64_t)v >> 62) != 1) { bad = true; return nullptr; }      // tagged pointers: bit 62 set, bit 63 clear
+    const int region = (int)((v >> 60) & 3);
+    const int64_t off = v & ((1ll << 60) - 1);
+    if (region == 0 && off <= h->workspace_bytes) return (char*)workspace_dev + off;
+    if (region == 1 && off <= h->weights_bytes) return (char*)weights_dev + off;
+    bad = true;
+    return nullptr;
+  };
+  if (hipMemset(workspace_dev, 0, (size_t)h->workspace_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    fdbm_set_error("fdbm_ncsnpp_create_from_program: zeroing the workspace failed");
+    return nullptr;
+  }
+  const fdbm_op* ops_in = reinterpret_cast<const fdbm_op*>(h + 1);
+  const fdbm_conv_args* conv_in = reinterpret_cast<const fdbm_conv_args*>(ops_in + h->n_ops);
+  fdbm_ncsnpp_ctx* c = new fdbm_ncsnpp_ctx;
+  c->ops = new fdbm_op[h->n_ops];
+  c->convs = new fdbm_conv_args[h->n_conv > 0 ? h->n_conv : 1];
+  memcpy(c->ops, ops_in, sizeof(fdbm_op) * (size_t)h->n_ops);
+  memcpy(c->convs, conv_in, sizeof(fdbm_conv_args) * (size_t)h->n_conv);
+  for (uint32_t i = 0; i < h->n_conv; ++i) {
+    fdbm_conv_args& a = c->convs[i];
+#define RL(f) a.f = (std::remove_reference_t<decltype((a.f))>)reloc((int64_t)(intptr_t)a.f)
+    for (int s = 0; s < FDBM_MAX_SEG; ++s) { RL(seg[s].src); RL(gn_seg_sums[s]); }
+    RL(w); RL(bias); RL(tbias); RL(res); RL(out); RL(workspace); RL(gn_sums); RL(gn_gamma); RL(gn_beta);
+    RL(comb_pyr); RL(comb_w); RL(comb_b); RL(stat_out); RL(w_frag); RL(acc_ws); RL(res_up2x);
+#undef RL
+  }
+  for (uint32_t i = 0; i < h->n_ops; ++i) {
+    fdbm_op& op = c->ops[i];
+    if (op.opcode == FDBM_OP_CONV) {
+      if (op.iarg[0] < 0 || op.iarg[0] >= (int64_t)h->n_conv) { bad = true; break; }
+      op.iarg[0] = (int64_t)(intptr_t)&c->convs[op.iarg[0]];
+      continue;
+    }
+    for (int j = 0; j < 24; ++j)
+      if (((uint64_t)op.iarg[j] >> 62) == 1) op.iarg[j] = (int64_t)(intptr_t)reloc(op.iarg[j]);   // (negative counts have bit 63 set)
+  }
+  c->n_ops = (int)h->n_ops;
+  c->x_in = reloc(h->x_in); c->y_in = reloc(h->y_in); c->logt_in = (float*)reloc(h->t_in); c->s_out = reloc(h->s_out);
+  c->n_complex = h->n_complex; c->B = h->B;
+  if (bad || !c->x_in || !c->y_in || !c->logt_in || !c->s_out) {
+    fdbm_set_error("fdbm_ncsnpp_create_from_program: a pointer of the program lies outside its regions");
+    fdbm_ncsnpp_destroy(c);
+    return nullptr;
+  }
+  if (fdbm_runtime_init_side() != 0) { fdbm_ncsnpp_destroy(c); return nullptr; }
+  return c;
 }
 
 // s = dnn(x, y, t): device pointers (complex64 [B][1][F][T] x2, f32 log t [B], complex64 out);

@@ -88,7 +88,8 @@ _SIGS = {
 }
 EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan",
                                 "fdbm_conv_plan_ex", "fdbm_conv_policy", "fdbm_conv_last_kind", "fdbm_runtime_init_side", "fdbm_ncsnpp_create", "fdbm_ncsnpp_destroy",
-                                "fdbm_ncsnpp_forward"])
+                                "fdbm_ncsnpp_forward", "fdbm_program_workspace_bytes", "fdbm_program_weights_bytes",
+                                "fdbm_ncsnpp_create_from_program"])
 
 
 def lib():
@@ -125,6 +126,12 @@ def lib():
         L.fdbm_ncsnpp_destroy.restype = None
         L.fdbm_ncsnpp_forward.argtypes = [c_void_p] * 6
         L.fdbm_ncsnpp_forward.restype = c_int
+        L.fdbm_program_workspace_bytes.argtypes = [c_void_p, c_i64]
+        L.fdbm_program_workspace_bytes.restype = c_i64
+        L.fdbm_program_weights_bytes.argtypes = [c_void_p, c_i64]
+        L.fdbm_program_weights_bytes.restype = c_i64
+        L.fdbm_ncsnpp_create_from_program.argtypes = [c_void_p, c_i64, c_void_p, c_void_p, c_i64]
+        L.fdbm_ncsnpp_create_from_program.restype = c_void_p
         _lib = L
     return _lib
 

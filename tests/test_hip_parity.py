@@ -254,3 +254,50 @@ def test_config4_fp16_batch16_sde_and_pc():
     a = br.sampler(m, y[:2], generator=torch.Generator().manual_seed(3), use_graph=True, **skw)
     b = br.sampler(m, y[:2], generator=torch.Generator().manual_seed(3), use_graph=False, **skw)
     assert torch.equal(torch.view_as_real(a), torch.view_as_real(b))
+
+
+def test_program_export_and_c_loader(tmp_path):
+    """a context from "a flat weight blob + architecture descriptor" with a caller-provided workspace and
+    size queries.  The recorded program of a network is serialised (fdbm_amd.export), loaded back through the C ABI into
+    a FRESH workspace and weight buffer (fdbm_ncsnpp_create_from_program) and evaluated with fdbm_ncsnpp_forward:
+    bit-identical to the Python-built context.  Then the C++ example host (examples/host_cpp) is compiled and run
+    on the exported files - no Python in that process - and must print the same checksum."""
+    import os, subprocess, ctypes
+    from fdbm_amd import hip
+    from fdbm_amd.export import export_program, load_program
+    hp = dict(nf=64, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,))
+    m = HipNCSNpp(dtype=torch.bfloat16, device=DEV, **hp)
+    g = torch.Generator().manual_seed(9)
+    x = torch.view_as_complex(torch.randn(1, 1, 257, 64, 2, generator=g)).to(DEV)
+    y = torch.view_as_complex(torch.randn(1, 1, 257, 64, 2, generator=g)).to(DEV)
+    ref = m(x, y, torch.tensor([0.5]).to(DEV))
+    program, weights = export_program(m.program(1, 257, 64))
+    L = hip.lib()
+    buf = ctypes.create_string_buffer(program, len(program))
+    assert L.fdbm_program_workspace_bytes(buf, 64) < 0                         # truncated: refused
+    ws = torch.empty(L.fdbm_program_workspace_bytes(buf, len(program)), dtype=torch.uint8, device=DEV)
+    wd = torch.frombuffer(bytearray(weights), dtype=torch.uint8).to(DEV)
+    ctx = load_program(program, wd, ws)
+    out = torch.empty_like(ref)
+    logt = torch.log(torch.tensor([0.5])).to(DEV)
+    assert L.fdbm_ncsnpp_forward(ctx, x.data_ptr(), y.data_ptr(), logt.data_ptr(), out.data_ptr(), hip.stream_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(out), torch.view_as_real(ref))
+    L.fdbm_ncsnpp_destroy(ctx)
+    # the C++ host
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.dirname(hip.LIB_PATH)
+    (tmp_path / "net.fdbmprog").write_bytes(program)
+    (tmp_path / "net.fdbmw").write_bytes(weights)
+    (tmp_path / "x.bin").write_bytes(torch.view_as_real(x).cpu().numpy().tobytes())
+    (tmp_path / "y.bin").write_bytes(torch.view_as_real(y).cpu().numpy().tobytes())
+    exe = tmp_path / "run_program"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "host_cpp", "run_program.cpp"), "-L", csrc, "-lfdbm_hip",
+                           f"-Wl,-rpath,{csrc}", "-o", str(exe)])
+    res = subprocess.run([str(exe), str(tmp_path / "net"), str(tmp_path / "x.bin"), str(tmp_path / "y.bin"), str(tmp_path / "s.bin")],
+                         capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr
+    import numpy as np
+    s = torch.from_numpy(np.frombuffer((tmp_path / "s.bin").read_bytes(), dtype=np.float32).copy()).reshape(ref.shape + (2,))
+    assert torch.equal(s, torch.view_as_real(ref).cpu()), res.stdout

@@ -699,7 +699,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     p.stat_out = a->stat_out; p.stat_G = a->stat_G; p.stat_nsplit = a->stat_nsplit;
   }
   hipStream_t st = (hipStream_t)stream;
-  if ((conv_policy() & 8) && (conv_policy() & 1) && a->dt_in != FDBM_F32 && fdbm_conv_ring_ok(p)) {
+  if ((conv_policy() & 8) && (conv_policy() & 1) && a->dt_in != FDBM_F32 && a->dt_out == a->dt_in && fdbm_conv_ring_ok(p)) {
     // producer / consumer ring kernel: one 512-thread workgroup per CU on a 16 x 16 pixel x 128 channel tile; wants
     // (nearly) a tile per CU, below that the halo-patch kernel's 8-row tiles fill the chip better
     static const char* rmin = getenv("FDBM_RING_MIN_TILES");   // experiments

@@ -24,6 +24,8 @@
 
 #include "conv_common.h"
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
 namespace ring {
 constexpr int PC = 18;                 // patch columns (16 + halo)
 constexpr int PROWS = 18 * 18;         // patch pixels
@@ -57,7 +59,7 @@ constexpr int NIT = 11;                // patch items (16 bytes) per producer th
 #endif
 
 template <typename T, typename TO, bool GNP>
-__global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int tiles_x, int tiles_y) {
+__global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int tiles_x, int tiles_y, int wgs_per_image) {
   using namespace ring;
   constexpr int KC = 64, VW = 8;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -65,23 +67,23 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
   float* s_gn = reinterpret_cast<float*>(smem + GOFF);                          // scale[gnpad] | shift[gnpad]
   double* s_stat = reinterpret_cast<double*>(smem + GOFF + gnpad * 8);          // [32][2]
   float* s_mr = reinterpret_cast<float*>(s_stat + 64);                          // [32][2] mean, rstd
+  float* s_cbt = s_mr + 64;                                                     // [128] bias + time-embedding bias of this (image, channel block)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, W = p.W;
-  // workgroups that share an XCD (blockIdx % 8) take neighbouring tiles: their halos meet in that XCD's L2
-  int tile;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int tx = tile % tiles_x;
-  const int ty = (tile / tiles_x) % tiles_y;
-  const int b = tile / (tiles_x * tiles_y);
-  const int y0 = ty * 16, x0 = tx * 16;
+  // PERSISTENT over the tiles of ONE image: workgroup (b, wslot) walks tiles wslot, wslot + wgs_per_image, ... of image b.
+  // The GroupNorm table (a property of the image) is built once; from the second tile on the prologue of a tile - its
+  // first patch, its first weight tiles - is staged by the producers while the consumers still multiply the tile before,
+  // and the tile's stores drain while the next one is computed.
+  const int tiles_per_image = tiles_x * tiles_y;
+  const int b = blockIdx.x / wgs_per_image;
+  const int wslot = blockIdx.x - b * wgs_per_image;
+  const int tile0 = wslot;
   const int n0 = blockIdx.y * 128;
   const int64_t img = (int64_t)b * H * W;
+  const int y0 = (tile0 / tiles_x) * 16, x0 = (tile0 % tiles_x) * 16;       // the first tile (patch 0 by all threads)
 
   if (p.stat_out && tid < 64) s_stat[tid] = 0.0;
 
@@ -148,20 +150,6 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
     RSTAMP(32, 256);
     const int ptid = tid - 256;
     const int pchunk = ptid & 7;
-    // item j of this thread = patch row (ptid / 8 + 32 j), source chunk pchunk, LDS position pchunk ^ key(row)
-    int ppix[NIT];          // pixel offset inside the image, -1: padding
-    int plds[NIT];          // row * 128 + ((pchunk ^ key) << 4)
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      const int row = (ptid >> 3) + 32 * j;
-      const int rr = min(row, PROWS - 1);
-      const int pr = rr / PC, pc = rr - pr * PC;
-      const int iy = y0 + pr - 1, ix = x0 + pc - 1;
-      const bool ok = row < PROWS && iy >= 0 && iy < H && ix >= 0 && ix < W;
-      ppix[j] = ok ? iy * W + ix : -1;
-      plds[j] = row * 128 + ((pchunk ^ ((pc >> 1) & 7)) << 4);
-    }
-
     // ---- weights: the 16 KiB tile of k-step k lives in register set k % 3 (4 x 16 bytes per thread: rows ptid/8 + 32 i,
     // chunk pchunk) and goes to ring slot k % 3; requested 3 intervals before it is written
     const int wg_off = (ptid >> 3) * 128 + pchunk * 16;
@@ -171,18 +159,17 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
     // (twelve named registers: as arrays handed to lambdas these sets were placed in scratch memory by hipcc)
     uint4 wa0, wa1, wa2, wa3, wb0_, wb1_, wb2_, wb3_, wc0, wc1, wc2, wc3;
     int w_seg = 0, w_c = 0, w_tap = 0, w_kbase = 0, w_step = 0;
-    // k index of the next k-step to request; advances the cursor.  Past the last k-step it keeps returning the last
-    // one: the loads below stay UNCONDITIONAL (a conditionally defined register set is placed in scratch memory by
-    // this compiler - every load then waited for on its own and stored to scratch), the surplus tiles are never written
+    // k index of the next k-step to request; advances the cursor, which WRAPS after the tile's last k-step: every tile
+    // of the layer streams the same weight tiles, so the requests of a tile's last three intervals already are the
+    // next tile's k-steps 0, 1, 2
     auto next_kidx = [&]() __attribute__((always_inline)) {
       const int nch = seg_nch(w_seg), ntaps = seg_taps(w_seg);
       const int kidx = w_kbase + w_tap * nch + w_c;
-      if (w_step + 1 < nsteps) {
-        ++w_step;
-        if (++w_tap == ntaps) {
-          w_tap = 0;
-          if (++w_c == nch) { w_c = 0; w_kbase += ntaps * nch; ++w_seg; }
-        }
+      if (++w_step == nsteps) {
+        w_step = 0; w_seg = 0; w_c = 0; w_tap = 0; w_kbase = 0;
+      } else if (++w_tap == ntaps) {
+        w_tap = 0;
+        if (++w_c == nch) { w_c = 0; w_kbase += ntaps * nch; ++w_seg; }
       }
       return kidx;
     };
@@ -209,11 +196,46 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
 #ifdef RING_X_NOWEIGHTS
       return;
 #endif
-      const bool wr = s + 1 < nsteps;
-      if constexpr (sl == 0) { if (wr) RING_WRITE_W(wa0, wa1, wa2, wa3, 0); RING_LOAD_W(wa0, wa1, wa2, wa3); }
-      else if constexpr (sl == 1) { if (wr) RING_WRITE_W(wb0_, wb1_, wb2_, wb3_, 1); RING_LOAD_W(wb0_, wb1_, wb2_, wb3_); }
-      else { if (wr) RING_WRITE_W(wc0, wc1, wc2, wc3, 2); RING_LOAD_W(wc0, wc1, wc2, wc3); }
+      // (the tile's last interval does neither: weights(nsteps) is the next tile's k-step 0, it stays in its set until
+      // the tile boundary puts it into slot 0)
+      if (s + 1 < nsteps) {
+        if constexpr (sl == 0) { RING_WRITE_W(wa0, wa1, wa2, wa3, 0); RING_LOAD_W(wa0, wa1, wa2, wa3); }
+        else if constexpr (sl == 1) { RING_WRITE_W(wb0_, wb1_, wb2_, wb3_, 1); RING_LOAD_W(wb0_, wb1_, wb2_, wb3_); }
+        else { RING_WRITE_W(wc0, wc1, wc2, wc3, 2); RING_LOAD_W(wc0, wc1, wc2, wc3); }
+      }
     };
+
+    // weights 0..2 are requested FIRST: their latency (the launch's first touch of the layer's weights) passes behind
+    // the integer work of the item tables below instead of in front of tick(-1)
+    RING_LOAD_W(wa0, wa1, wa2, wa3);
+    RING_LOAD_W(wb0_, wb1_, wb2_, wb3_);
+    RING_LOAD_W(wc0, wc1, wc2, wc3);
+    // item j of this thread = patch row (ptid / 8 + 32 j), source chunk pchunk, LDS position pchunk ^ key(row).
+    // Pixel offsets of the CURRENT tile (ppix) and of the NEXT one (ppixn: the patches staged / requested across a tile
+    // boundary belong to it), -1: padding; the LDS position is the same for every tile.
+    int ppix[NIT], ppixn[NIT];
+    int plds[NIT];          // row * 128 + ((pchunk ^ key) << 4)
+    // (a value-returning helper, filled in by unrolled loops: handed to a lambda by reference the tables were placed in
+    // scratch memory)
+    auto ppix_of = [&](int j, int ti) __attribute__((always_inline)) {
+      const int ty_ = ti / tiles_x, tx_ = ti - ty_ * tiles_x;
+      const int row = (ptid >> 3) + 32 * j;
+      const int rr = min(row, PROWS - 1);
+      const int pr = rr / PC, pc = rr - pr * PC;
+      const int iy = ty_ * 16 + pr - 1, ix = tx_ * 16 + pc - 1;
+      const bool ok = row < PROWS && iy >= 0 && iy < H && ix >= 0 && ix < W;
+      return ok ? iy * W + ix : -1;
+    };
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) { ppix[j] = ppix_of(j, tile0); ppixn[j] = ppix[j]; }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int row = (ptid >> 3) + 32 * j;
+      const int rr = min(row, PROWS - 1);
+      const int pc = rr % PC;
+      plds[j] = row * 128 + ((pchunk ^ ((pc >> 1) & 7)) << 4);
+    }
+    int cy0 = y0, cx0 = x0;      // the current tile's origin (the tail's interior patches)
 
     // ---- patch staging of chunk (s, c) through registers
     uint4 preg[NIT];
@@ -233,9 +255,13 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       pcok_next = pchunk * VW < cvalid;
       psrc_next = patch_src(s, c, pcok_next ? pchunk : 0);
     };
-    auto load_item = [&](auto JJ) __attribute__((always_inline)) {
+    // (nt: the patch belongs to the NEXT tile of this workgroup)
+    auto load_item = [&](auto JJ, bool nt) __attribute__((always_inline)) {
       constexpr int j = decltype(JJ)::value;
-      preg[j] = *reinterpret_cast<const uint4*>(psrc_next + (int64_t)max(ppix[j], 0) * pC_next);
+      // (two loads of VALUES, then a select: `nt ? ppixn[j] : ppix[j]` selects between two addresses and keeps both
+      // tables in scratch memory)
+      const int pa_ = ppix[j], pn_ = ppixn[j];
+      preg[j] = *reinterpret_cast<const uint4*>(psrc_next + (int64_t)max(nt ? pn_ : pa_, 0) * pC_next);
     };
     auto load_scale_shift = [&](int s, int c) __attribute__((always_inline)) {
       if constexpr (GNP) {
@@ -249,13 +275,14 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
     };
     // GroupNorm + SiLU of item j in place (registers only: this is the part of an interval that runs AFTER its LDS
     // writes have been issued), and its write one interval later
-    auto xform_item = [&](auto JJ, bool xform) __attribute__((always_inline)) {
+    auto xform_item = [&](auto JJ, bool xform, bool nt) __attribute__((always_inline)) {
       constexpr int j = decltype(JJ)::value;
       uint4 v = preg[j];
 #ifndef RING_X_NOXFORM
       if constexpr (GNP) { if (xform) v = gn_transform16<T>(v, tsc, tsh, p.gn_silu != 0); }
 #endif
-      if (!(ppix[j] >= 0 && pcok)) v = uint4{0u, 0u, 0u, 0u};            // padding AFTER the activation
+      const int pa_ = ppix[j], pn_ = ppixn[j];
+      if (!((nt ? pn_ : pa_) >= 0 && pcok)) v = uint4{0u, 0u, 0u, 0u};            // padding AFTER the activation
       preg[j] = v;
     };
     auto write_item = [&](auto JJ, int buf) __attribute__((always_inline)) {
@@ -280,7 +307,7 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int r = (ptid >> 3) + 32 * j;                    // interior pixel: row r / 16, column r % 16 (always inside the image)
-        tp[j] = *reinterpret_cast<const uint4*>(src + (int64_t)((y0 + (r >> 4)) * W + x0 + (r & 15)) * sg_C);
+        tp[j] = *reinterpret_cast<const uint4*>(src + (int64_t)((cy0 + (r >> 4)) * W + cx0 + (r & 15)) * sg_C);
       }
     };
     auto tail_store = [&](const uint4 (&tp)[8], bool cok, int buf) __attribute__((always_inline)) {
@@ -295,9 +322,6 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
 
     // ---- prologue: weights 0..3 requested, weights 0 written; patch 0 by all threads -----------------------------
     RSTAMP(33, 256);
-    RING_LOAD_W(wa0, wa1, wa2, wa3);
-    RING_LOAD_W(wb0_, wb1_, wb2_, wb3_);
-    RING_LOAD_W(wc0, wc1, wc2, wc3);
     RSTAMP(34, 256);
     if constexpr (GNP) conv_gn_table<512>(p, b, 1, s_gn, gnpad, s_mr, smem + PB);
     RSTAMP(35, 256);
@@ -310,10 +334,10 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       if (c1 == sg_n0) { c1 = 0; s1 = 1; }
       if (s1 >= nseg) { s1 = 0; c1 = 0; }
       patch_request_begin(s1, c1);
-      load_item(std::integral_constant<int, 0>{}); load_item(std::integral_constant<int, 1>{}); load_item(std::integral_constant<int, 2>{});
-      load_item(std::integral_constant<int, 3>{}); load_item(std::integral_constant<int, 4>{}); load_item(std::integral_constant<int, 5>{});
-      load_item(std::integral_constant<int, 6>{}); load_item(std::integral_constant<int, 7>{}); load_item(std::integral_constant<int, 8>{});
-      load_item(std::integral_constant<int, 9>{}); load_item(std::integral_constant<int, 10>{});
+      load_item(std::integral_constant<int, 0>{}, false); load_item(std::integral_constant<int, 1>{}, false); load_item(std::integral_constant<int, 2>{}, false);
+      load_item(std::integral_constant<int, 3>{}, false); load_item(std::integral_constant<int, 4>{}, false); load_item(std::integral_constant<int, 5>{}, false);
+      load_item(std::integral_constant<int, 6>{}, false); load_item(std::integral_constant<int, 7>{}, false); load_item(std::integral_constant<int, 8>{}, false);
+      load_item(std::integral_constant<int, 9>{}, false); load_item(std::integral_constant<int, 10>{}, false);
     }
     RSTAMP(36, 256);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -331,112 +355,184 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
     if (nseg > 1) { n9 += sg_t1 == 9 ? sg_n1 : 0; n1 += sg_t1 == 1 ? sg_n1 : 0; }
     if (nseg > 2) { n9 += sg_t2 == 9 ? sg_n2 : 0; n1 += sg_t2 == 1 ? sg_n2 : 0; }
     if (nseg > 3) { n9 += sg_t3 == 9 ? sg_n3 : 0; n1 += sg_t3 == 1 ? sg_n3 : 0; }
-    int cs = 0, cc = 0, pb = 0, sbase = 0;
-    // (ns, nc): the chunk after (cs, cc)
-    auto chunk_after = [&](int s_, int c_, int& ns_, int& nc_) __attribute__((always_inline)) {
+    int pb = 0;
+    // (ns, nc): the chunk after (s_, c_); wraps to the next tile's chunk (0, 0) behind the tile's last chunk
+    auto chunk_after = [&](int s_, int c_, int& ns_, int& nc_, bool& wrapped) __attribute__((always_inline)) {
       ns_ = s_; nc_ = c_ + 1;
       if (nc_ == seg_nch(s_)) { nc_ = 0; ns_ = s_ + 1; }
+      if (ns_ == nseg) { ns_ = 0; wrapped = true; }
     };
-    // An interval = [LDS writes of what was prepared before: weights(s + 1), the patch items transformed in the previous
-    // interval] -> [requests: weights(s + 4), at t = 7 / 8 the patch after the next one] -> [GroupNorm + SiLU of this
-    // interval's items, registers only] -> tick.  The writes come FIRST so that they have completed by the time the
-    // arithmetic is done: with the write at the end of the interval its completion latency (behind the consumers' LDS
-    // reads) sat in front of every tick.  Items: transformed in intervals 0..7 (2,1,1,2,1,1,2,1), written one later.
-    for (int ci = 0; ci < n9; ++ci) {
-      int ns, nc, s2, c2;
-      chunk_after(cs, cc, ns, nc);
-      chunk_after(ns, nc, s2, c2);
-      const bool has_next = ns < nseg;
-      const bool nreg = has_next && is_reg(ns);
-      // the patch requested during this chunk's last two intervals: the chunk after the next one (none left: this
-      // chunk's again, dropped)
-      const bool req = s2 < nseg;
-      pcok = pcok_next;
-      auto interval = [&](auto TT) __attribute__((always_inline)) {
-        constexpr int t = decltype(TT)::value;
-        weights_interval(std::integral_constant<int, t % 3>{}, sbase + t);
-        if (has_next) {
-          if constexpr (t == 1) { write_item(std::integral_constant<int, 0>{}, pb ^ 1); write_item(std::integral_constant<int, 1>{}, pb ^ 1); }
-          if constexpr (t == 2) write_item(std::integral_constant<int, 2>{}, pb ^ 1);
-          if constexpr (t == 3) write_item(std::integral_constant<int, 3>{}, pb ^ 1);
-          if constexpr (t == 4) { write_item(std::integral_constant<int, 4>{}, pb ^ 1); write_item(std::integral_constant<int, 5>{}, pb ^ 1); }
-          if constexpr (t == 5) write_item(std::integral_constant<int, 6>{}, pb ^ 1);
-          if constexpr (t == 6) write_item(std::integral_constant<int, 7>{}, pb ^ 1);
-          if constexpr (t == 7) { write_item(std::integral_constant<int, 8>{}, pb ^ 1); write_item(std::integral_constant<int, 9>{}, pb ^ 1); }
-          if constexpr (t == 8) write_item(std::integral_constant<int, 10>{}, pb ^ 1);
-        }
-        // (unconditional loads, see next_kidx)
-        if constexpr (t == 7) {
-          patch_request_begin(req ? s2 : cs, req ? c2 : cc);
-          load_item(std::integral_constant<int, 0>{}); load_item(std::integral_constant<int, 1>{}); load_item(std::integral_constant<int, 2>{});
-          load_item(std::integral_constant<int, 3>{}); load_item(std::integral_constant<int, 4>{}); load_item(std::integral_constant<int, 5>{});
-          load_item(std::integral_constant<int, 6>{}); load_item(std::integral_constant<int, 7>{});
-        }
-        if constexpr (t == 8) {
-          load_item(std::integral_constant<int, 8>{}); load_item(std::integral_constant<int, 9>{}); load_item(std::integral_constant<int, 10>{});
-        }
-        if constexpr (t == 0) { if (nreg) load_scale_shift(ns, nc); }
-        if constexpr (t == 0) { xform_item(std::integral_constant<int, 0>{}, nreg); xform_item(std::integral_constant<int, 1>{}, nreg); }
-        if constexpr (t == 1) xform_item(std::integral_constant<int, 2>{}, nreg);
-        if constexpr (t == 2) xform_item(std::integral_constant<int, 3>{}, nreg);
-        if constexpr (t == 3) { xform_item(std::integral_constant<int, 4>{}, nreg); xform_item(std::integral_constant<int, 5>{}, nreg); }
-        if constexpr (t == 4) xform_item(std::integral_constant<int, 6>{}, nreg);
-        if constexpr (t == 5) xform_item(std::integral_constant<int, 7>{}, nreg);
-        if constexpr (t == 6) { xform_item(std::integral_constant<int, 8>{}, nreg); xform_item(std::integral_constant<int, 9>{}, nreg); }
-        if constexpr (t == 7) xform_item(std::integral_constant<int, 10>{}, nreg);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // tick
-      };
-      interval(std::integral_constant<int, 0>{}); interval(std::integral_constant<int, 1>{});
-      interval(std::integral_constant<int, 2>{}); interval(std::integral_constant<int, 3>{});
-      interval(std::integral_constant<int, 4>{}); interval(std::integral_constant<int, 5>{});
-      interval(std::integral_constant<int, 6>{}); interval(std::integral_constant<int, 7>{});
-      interval(std::integral_constant<int, 8>{});
-      pb ^= 1;
-      cs = ns; cc = nc;
-      sbase += 9;
-      RSTAMP(pstamp, 256);
-      if (pstamp < 60) ++pstamp;
-    }
-    // ---- 1-tap chunks: tail chunk e runs in interval e; its interval writes the patch of chunk e + 1 (set (e+1) % 3,
-    // requested one interval earlier) into the other buffer and requests the patch of chunk e + 2 (set (e+2) % 3).
-    // The patch of tail chunk 1 is requested here (one exposed load latency per launch, instead of three more register
-    // sets alive across the whole 9-tap loop); every request is unconditional, clamped to an existing chunk.
-    {
-      int s1 = cs, c1 = cc;
-      if (n1 >= 2) chunk_after(cs, cc, s1, c1);
-      tail_load(tp1, tcok1, min(s1, nseg - 1), s1 < nseg ? c1 : 0);
-      tail_load(tp2, tcok2, min(s1, nseg - 1), s1 < nseg ? c1 : 0);
-      tail_load(tp0, tcok0, min(s1, nseg - 1), s1 < nseg ? c1 : 0);
-    }
-    for (int e0 = 0; e0 < n1; e0 += 3) {
-      auto tail_interval = [&](auto EE) __attribute__((always_inline)) {
-        constexpr int em = decltype(EE)::value;        // e % 3
-        const int e = e0 + em;
-        if (e < n1) {
-          weights_interval(std::integral_constant<int, em>{}, sbase + e);
-          int s1, c1, s2, c2;
-          chunk_after(cs, cc, s1, c1);
-          chunk_after(s1, c1, s2, c2);
-          if (e + 1 < n1) {
-            if constexpr (em == 0) tail_store(tp1, tcok1, pb ^ 1); else if constexpr (em == 1) tail_store(tp2, tcok2, pb ^ 1); else tail_store(tp0, tcok0, pb ^ 1);
+    const int wrot = nsteps % 3;
+    for (int ti = tile0; ti < tiles_per_image; ti += wgs_per_image) {
+      const bool last_tile = ti + wgs_per_image >= tiles_per_image;
+      int cs = 0, cc = 0, sbase = 0;
+      if (!last_tile) {
+        // (the next tile's table: first used by the patch requests of this tile's last chunks)
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) ppixn[j] = ppix_of(j, ti + wgs_per_image);
+      }
+      // An interval = [LDS writes of what was prepared before: weights(s + 1), the patch items transformed in the previous
+      // interval] -> [requests: weights(s + 4), at t = 7 / 8 the patch after the next one] -> [GroupNorm + SiLU of this
+      // interval's items, registers only] -> tick.  The writes come FIRST so that they have completed by the time the
+      // arithmetic is done: with the write at the end of the interval its completion latency (behind the consumers' LDS
+      // reads) sat in front of every tick.  Items: transformed in intervals 0..7 (2,1,1,2,1,1,2,1), written one later.
+      for (int ci = 0; ci < n9; ++ci) {
+        int ns, nc, s2, c2;
+        bool w1 = false, w2 = false;
+        chunk_after(cs, cc, ns, nc, w1);
+        w2 = w1;
+        chunk_after(ns, nc, s2, c2, w2);
+        // the chunk after this one: of this tile, or (no tail) the next tile's first - unless this is the last tile
+        const bool has_next = !(w1 && last_tile);
+        const bool nreg = has_next && is_reg(ns);
+        // the patch requested during this chunk's last two intervals: the chunk after the next one.  Nothing to
+        // request (this chunk's again, dropped): behind the last tile, or where the 1-tap tail requests its own patches
+        const bool req = !(w2 && last_tile) && !(n1 > 0 && ci == n9 - 1);
+        const bool req_nt = w2;
+        pcok = pcok_next;
+        auto interval = [&](auto TT) __attribute__((always_inline)) {
+          constexpr int t = decltype(TT)::value;
+          weights_interval(std::integral_constant<int, t % 3>{}, sbase + t);
+          if (has_next) {
+            if constexpr (t == 1) { write_item(std::integral_constant<int, 0>{}, pb ^ 1); write_item(std::integral_constant<int, 1>{}, pb ^ 1); }
+            if constexpr (t == 2) write_item(std::integral_constant<int, 2>{}, pb ^ 1);
+            if constexpr (t == 3) write_item(std::integral_constant<int, 3>{}, pb ^ 1);
+            if constexpr (t == 4) { write_item(std::integral_constant<int, 4>{}, pb ^ 1); write_item(std::integral_constant<int, 5>{}, pb ^ 1); }
+            if constexpr (t == 5) write_item(std::integral_constant<int, 6>{}, pb ^ 1);
+            if constexpr (t == 6) write_item(std::integral_constant<int, 7>{}, pb ^ 1);
+            if constexpr (t == 7) { write_item(std::integral_constant<int, 8>{}, pb ^ 1); write_item(std::integral_constant<int, 9>{}, pb ^ 1); }
+            if constexpr (t == 8) write_item(std::integral_constant<int, 10>{}, pb ^ 1);
           }
-          {
-            const bool more = e + 2 < n1;
-            const int sl = more ? s2 : cs, cl = more ? c2 : cc;
-            if constexpr (em == 0) tail_load(tp2, tcok2, sl, cl); else if constexpr (em == 1) tail_load(tp0, tcok0, sl, cl); else tail_load(tp1, tcok1, sl, cl);
+          // (unconditional loads)
+          if constexpr (t == 7) {
+            patch_request_begin(req ? s2 : cs, req ? c2 : cc);
+            const bool nt = req && req_nt;
+            load_item(std::integral_constant<int, 0>{}, nt); load_item(std::integral_constant<int, 1>{}, nt); load_item(std::integral_constant<int, 2>{}, nt);
+            load_item(std::integral_constant<int, 3>{}, nt); load_item(std::integral_constant<int, 4>{}, nt); load_item(std::integral_constant<int, 5>{}, nt);
+            load_item(std::integral_constant<int, 6>{}, nt); load_item(std::integral_constant<int, 7>{}, nt);
           }
+          if constexpr (t == 8) {
+            const bool nt = req && req_nt;
+            load_item(std::integral_constant<int, 8>{}, nt); load_item(std::integral_constant<int, 9>{}, nt); load_item(std::integral_constant<int, 10>{}, nt);
+          }
+          if constexpr (t == 0) { if (nreg) load_scale_shift(ns, nc); }
+          if constexpr (t == 0) { xform_item(std::integral_constant<int, 0>{}, nreg, w1); xform_item(std::integral_constant<int, 1>{}, nreg, w1); }
+          if constexpr (t == 1) xform_item(std::integral_constant<int, 2>{}, nreg, w1);
+          if constexpr (t == 2) xform_item(std::integral_constant<int, 3>{}, nreg, w1);
+          if constexpr (t == 3) { xform_item(std::integral_constant<int, 4>{}, nreg, w1); xform_item(std::integral_constant<int, 5>{}, nreg, w1); }
+          if constexpr (t == 4) xform_item(std::integral_constant<int, 6>{}, nreg, w1);
+          if constexpr (t == 5) xform_item(std::integral_constant<int, 7>{}, nreg, w1);
+          if constexpr (t == 6) { xform_item(std::integral_constant<int, 8>{}, nreg, w1); xform_item(std::integral_constant<int, 9>{}, nreg, w1); }
+          if constexpr (t == 7) xform_item(std::integral_constant<int, 10>{}, nreg, w1);
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();   // tick
-          pb ^= 1;
-          cs = s1; cc = c1;
+        };
+        interval(std::integral_constant<int, 0>{}); interval(std::integral_constant<int, 1>{});
+        interval(std::integral_constant<int, 2>{}); interval(std::integral_constant<int, 3>{});
+        interval(std::integral_constant<int, 4>{}); interval(std::integral_constant<int, 5>{});
+        interval(std::integral_constant<int, 6>{}); interval(std::integral_constant<int, 7>{});
+        interval(std::integral_constant<int, 8>{});
+        pb ^= 1;
+        cs = ns; cc = nc;
+        sbase += 9;
+        RSTAMP(pstamp, 256);
+        if (pstamp < 60) ++pstamp;
+      }
+      // ---- 1-tap chunks: tail chunk e runs in interval e; its interval writes the patch of chunk e + 1 (set (e+1) % 3,
+      // requested one interval earlier) into the other buffer and requests the patch of chunk e + 2 (set (e+2) % 3).
+      // The patch of tail chunk 1 is requested here (one exposed load latency per tile, instead of three more register
+      // sets alive across the whole 9-tap loop); every request is unconditional, clamped to an existing chunk.
+      if (n1 > 0) {
+        int s1 = cs, c1 = cc;
+        bool wdummy = false;
+        if (n1 >= 2) chunk_after(cs, cc, s1, c1, wdummy);
+        tail_load(tp1, tcok1, s1, c1);
+        tail_load(tp2, tcok2, s1, c1);
+        tail_load(tp0, tcok0, s1, c1);
+      }
+      for (int e0 = 0; e0 < n1; e0 += 3) {
+        auto tail_interval = [&](auto EE) __attribute__((always_inline)) {
+          constexpr int em = decltype(EE)::value;        // e % 3
+          const int e = e0 + em;
+          if (e < n1) {
+            weights_interval(std::integral_constant<int, em>{}, sbase + e);
+            int s1, c1, s2, c2;
+            bool wd = false;
+            chunk_after(cs, cc, s1, c1, wd);
+            chunk_after(s1, c1, s2, c2, wd);
+            if (e + 1 < n1) {
+              if constexpr (em == 0) tail_store(tp1, tcok1, pb ^ 1); else if constexpr (em == 1) tail_store(tp2, tcok2, pb ^ 1); else tail_store(tp0, tcok0, pb ^ 1);
+            }
+            {
+              const bool more = e + 2 < n1;
+              const int sl = more ? s2 : cs, cl = more ? c2 : cc;
+              if constexpr (em == 0) tail_load(tp2, tcok2, sl, cl); else if constexpr (em == 1) tail_load(tp0, tcok0, sl, cl); else tail_load(tp1, tcok1, sl, cl);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();   // tick
+            pb ^= 1;
+            cs = s1; cc = c1;
+          }
+        };
+        tail_interval(std::integral_constant<int, 0>{});
+        tail_interval(std::integral_constant<int, 1>{});
+        tail_interval(std::integral_constant<int, 2>{});
+      }
+      // ---- tile boundary (the consumers are in the tile's second-to-last half / its epilogue) ---------------------------
+      if (!last_tile) {
+        // weights: k-steps 0, 1, 2 of the next tile were requested by this tile's last intervals into the sets
+        // (nsteps + j) % 3; back to "k-step j in set j", k-step 0 into ring slot 0, k-step 3 requested
+        if (wrot == 1) {
+          uint4 t0 = wa0, t1 = wa1, t2 = wa2, t3 = wa3;
+          wa0 = wb0_; wa1 = wb1_; wa2 = wb2_; wa3 = wb3_;
+          wb0_ = wc0; wb1_ = wc1; wb2_ = wc2; wb3_ = wc3;
+          wc0 = t0; wc1 = t1; wc2 = t2; wc3 = t3;
+        } else if (wrot == 2) {
+          uint4 t0 = wa0, t1 = wa1, t2 = wa2, t3 = wa3;
+          wa0 = wc0; wa1 = wc1; wa2 = wc2; wa3 = wc3;
+          wc0 = wb0_; wc1 = wb1_; wc2 = wb2_; wc3 = wb3_;
+          wb0_ = t0; wb1_ = t1; wb2_ = t2; wb3_ = t3;
         }
-      };
-      tail_interval(std::integral_constant<int, 0>{});
-      tail_interval(std::integral_constant<int, 1>{});
-      tail_interval(std::integral_constant<int, 2>{});
+        RING_WRITE_W(wa0, wa1, wa2, wa3, 0);
+        RING_LOAD_W(wa0, wa1, wa2, wa3);
+        if (n1 > 0) {
+          // behind a 1-tap tail the next tile's first patch is staged here, in one piece (the main pipeline's registers
+          // went to the tail's first patch): one exposed load + 11 items per tile of a layer with a shortcut segment
+          patch_request_begin(0, 0);
+          load_item(std::integral_constant<int, 0>{}, true); load_item(std::integral_constant<int, 1>{}, true); load_item(std::integral_constant<int, 2>{}, true);
+          load_item(std::integral_constant<int, 3>{}, true); load_item(std::integral_constant<int, 4>{}, true); load_item(std::integral_constant<int, 5>{}, true);
+          load_item(std::integral_constant<int, 6>{}, true); load_item(std::integral_constant<int, 7>{}, true); load_item(std::integral_constant<int, 8>{}, true);
+          load_item(std::integral_constant<int, 9>{}, true); load_item(std::integral_constant<int, 10>{}, true);
+          pcok = pcok_next;
+          const bool r0 = is_reg(0);
+          if (r0) load_scale_shift(0, 0);
+          xform_item(std::integral_constant<int, 0>{}, r0, true); xform_item(std::integral_constant<int, 1>{}, r0, true); xform_item(std::integral_constant<int, 2>{}, r0, true);
+          xform_item(std::integral_constant<int, 3>{}, r0, true); xform_item(std::integral_constant<int, 4>{}, r0, true); xform_item(std::integral_constant<int, 5>{}, r0, true);
+          xform_item(std::integral_constant<int, 6>{}, r0, true); xform_item(std::integral_constant<int, 7>{}, r0, true); xform_item(std::integral_constant<int, 8>{}, r0, true);
+          xform_item(std::integral_constant<int, 9>{}, r0, true); xform_item(std::integral_constant<int, 10>{}, r0, true);
+          write_item(std::integral_constant<int, 0>{}, pb); write_item(std::integral_constant<int, 1>{}, pb); write_item(std::integral_constant<int, 2>{}, pb);
+          write_item(std::integral_constant<int, 3>{}, pb); write_item(std::integral_constant<int, 4>{}, pb); write_item(std::integral_constant<int, 5>{}, pb);
+          write_item(std::integral_constant<int, 6>{}, pb); write_item(std::integral_constant<int, 7>{}, pb); write_item(std::integral_constant<int, 8>{}, pb);
+          write_item(std::integral_constant<int, 9>{}, pb); write_item(std::integral_constant<int, 10>{}, pb);
+          // and the patch of its chunk 1 requested (clamped to chunk 0 where the layer has a single chunk)
+          int s1 = 0, c1 = 1;
+          if (c1 == sg_n0) { c1 = 0; s1 = 1; }
+          if (s1 >= nseg) { s1 = 0; c1 = 0; }
+          patch_request_begin(s1, c1);
+          load_item(std::integral_constant<int, 0>{}, true); load_item(std::integral_constant<int, 1>{}, true); load_item(std::integral_constant<int, 2>{}, true);
+          load_item(std::integral_constant<int, 3>{}, true); load_item(std::integral_constant<int, 4>{}, true); load_item(std::integral_constant<int, 5>{}, true);
+          load_item(std::integral_constant<int, 6>{}, true); load_item(std::integral_constant<int, 7>{}, true); load_item(std::integral_constant<int, 8>{}, true);
+          load_item(std::integral_constant<int, 9>{}, true); load_item(std::integral_constant<int, 10>{}, true);
+        }
+        // the next tile becomes the current one
+        const int tn = ti + wgs_per_image;
+#pragma unroll
+        for (int j = 0; j < NIT; ++j) ppix[j] = ppixn[j];
+        cy0 = (tn / tiles_x) * 16; cx0 = (tn % tiles_x) * 16;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();       // tile boundary (also the consumers' statistics exchange)
     }
-    if (p.stat_out) __builtin_amdgcn_s_barrier();     // the consumers' statistics exchange
     return;
   }
 
@@ -446,10 +542,6 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
   const int wm = wave >> 1, wn = wave & 1;
   const int frow = lane & 15, fk = lane >> 4;
   f32x4 acc[4][8];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // per-lane fragment bases: (patch row wm*8 [+ i + dy], column frow + dx, k-half kk) and (weight row wn*64 [+ 16 j] + frow)
 #define A_BASE(DX, KK) ((wm * 8 * PC + frow + (DX)) * 128 + ((((KK) * 4 + fk) ^ (((frow + (DX)) >> 1) & 7)) << 4))
@@ -503,6 +595,16 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
   };
 
   RSTAMP(1, 0);
+  if (tid < 128) {
+    // per-channel additive constants of the epilogue, once per workgroup (published by tick(-1))
+    const int n = n0 + tid;
+    float v = 0.f;
+    if (n < p.Cout) {
+      if (p.bias) v = p.bias[n];
+      if (p.tbias) v += p.tbias[(int64_t)b * p.tbias_stride + n];
+    }
+    s_cbt[tid] = v;
+  }
   if constexpr (GNP) conv_gn_table<512>(p, b, 1, s_gn, gnpad, s_mr, smem + PB);
   RSTAMP(2, 0);
   p0_store();
@@ -523,7 +625,15 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
   if (nseg > 1) { n9 += sg_t1 == 9 ? sg_n1 : 0; n1 += sg_t1 == 1 ? sg_n1 : 0; }
   if (nseg > 2) { n9 += sg_t2 == 9 ? sg_n2 : 0; n1 += sg_t2 == 1 ? sg_n2 : 0; }
   if (nseg > 3) { n9 += sg_t3 == 9 ? sg_n3 : 0; n1 += sg_t3 == 1 ? sg_n3 : 0; }
+  for (int ti = tile0; ti < tiles_per_image; ti += wgs_per_image) {
+  const int tile = ti;
+  const int y0 = (ti / tiles_x) * 16, x0 = (ti % tiles_x) * 16;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
   {
+    // (behind tick(-1) / the tile boundary: the tile's first patch and weight tile 0 are in LDS)
     rd_w(fa0, wb0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) fb[i] = *reinterpret_cast<const uint4*>(smem + ab00 + i * (PC * 128));
@@ -566,176 +676,128 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       ab00 += dflip; ab01 += dflip; ab10 += dflip; ab11 += dflip; ab20 += dflip; ab21 += dflip;
     }
   }
-  __builtin_amdgcn_s_setprio(0);
   RSTAMP(20, 0);
 
   // ---- epilogue -------------------------------------------------------------------------------------------------
-  // Lane (frow, fk) holds channels n_j .. n_j+3 (n_j = n0 + wn*64 + 16 j + 4 fk) of pixel (y0 + wm*8 + i, x0 + frow).
+  // Lane (frow_e, fk_e) holds channels n_j .. n_j+3 (n_j = n0 + wn*64 + 16 j + 4 fk_e) of pixel (y0 + wm*8 + i, x0 + frow_e).
   // No memory operation sits behind a per-element branch (a conditional load makes hipcc wait for each one
   // separately: 32 serialised round trips, 13 us of a 30 us launch): per-channel constants are fetched once, the
   // residual in batches of 16 unconditional loads, and with bf16 output the lanes of a DPP row pair exchange halves
   // (v_permlane16_swap) so that every lane owns 8 consecutive channels: 16-byte loads / stores, half the instructions.
+  // (lane coordinates made opaque per tile: with them loop-invariant hipcc hoists some forty 64-bit addresses of the
+  // epilogue out of the tile loop and spills them around the k-loop)
+  int frow_e = frow, fk_e = fk;
+  asm volatile("" : "+v"(frow_e), "+v"(fk_e));
   const int Cout = p.Cout;
   const bool do_stat = p.stat_out != nullptr;
   const int scpg = do_stat ? Cout / p.stat_G : 1;
   float a1[4], a2[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) a1[j] = a2[j] = 0.f;
-  if (p.res_lo || p.comb_pyr) {
-    // rare forms (pyramid heads, Combine): the shared per-element epilogue
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int y = y0 + wm * 8 + i, x = x0 + frow;
-      const int64_t m = img + (int64_t)y * W + x;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int n = n0 + wn * 64 + j * 16 + fk * 4;
-        float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
-        const bool live = n < Cout;
-        if (live) conv_epilogue4<TO>(p, m, b, n, v);
-        if (do_stat && live) {
-          a1[j] += (v[0] + v[1]) + (v[2] + v[3]);
-          a2[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-        }
-      }
-    }
-  } else {
-    f32x4 cb[4], ct[4];
+  static_assert(sizeof(TO) == 2, "the ring kernel stores 16-bit tensors (fdbm_conv_ring_ok)");
+  {
+    // ONE form (fdbm_conv_ring_ok: 16-bit output, Cout a multiple of 8, no pyramid / Combine extras): bias, time bias,
+    // residual, scale, statistics.  Kept short, because nothing overlaps it - the workgroup's producers wait at the tile
+    // boundary: packed f32 arithmetic, the additive constants from LDS, buffer addressing (ONE 32-bit offset register
+    // for the 16 stores and the 16 residual loads: row = scalar offset, channel pair = immediate), and the lanes of a
+    // DPP row pair exchange halves (v_permlane16_swap) so that every lane owns 8 consecutive channels: 16-byte loads /
+    // stores.  No memory operation sits behind a per-element branch (hipcc waits for each such load separately).
+    using X4 = typename V16<TO>::x4;
+    const uint32_t rowB = (uint32_t)W * (uint32_t)Cout * 2u;
+    const bool has_r = p.res != nullptr;
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<TO*>(p.out) + img * Cout, 0, (int)((uint32_t)H * rowB), 0x00020000);
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<TO*>(reinterpret_cast<const TO*>(has_r ? p.res : p.out)) + img * Cout, 0, (int)((uint32_t)H * rowB), 0x00020000);
+    // after the exchange the lane in DPP row fk_e owns channels [16 (2 q + (fk_e & 1)) + 8 (fk_e >> 1), + 8) of pair q
+    const int nq = n0 + wn * 64 + (fk_e & 1) * 16 + (fk_e >> 1) * 8;
+    const uint32_t voff = (uint32_t)((y0 + wm * 8) * W + x0 + frow_e) * (uint32_t)Cout * 2u + (uint32_t)nq * 2u;
+    const bool okq0 = nq < Cout, okq1 = nq + 32 < Cout;
+    f32x2 cl[4], ch[4], s1[4], s2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = min(n0 + wn * 64 + j * 16 + fk * 4, Cout - 4);
-      cb[j] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-      ct[j] = p.tbias ? *reinterpret_cast<const f32x4*>(p.tbias + (int64_t)b * p.tbias_stride + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+      const f32x4 c = *reinterpret_cast<const f32x4*>(s_cbt + wn * 64 + j * 16 + fk_e * 4);
+      cl[j] = f32x2{c[0], c[1]}; ch[j] = f32x2{c[2], c[3]};
+      s1[j] = s2[j] = f32x2{0.f, 0.f};
     }
-    const bool has_b = p.bias != nullptr, has_t = p.tbias != nullptr, has_r = p.res != nullptr;
-    const float scale = p.scale;
-    constexpr bool WIDE = sizeof(TO) == 2;
-    const bool wide = WIDE && (Cout & 7) == 0;
-    // wide form: after the exchange the lane in DPP row fk owns channels [16 (2 q + (fk & 1)) + 8 (fk >> 1), + 8) of
-    // pair q = tiles (2q, 2q+1)
-    const int64_t pix0 = img + (int64_t)(y0 + wm * 8) * W + x0 + frow;
-    constexpr int RB = WIDE ? 4 : 2;       // rows per batch of residual loads (f32: 16-byte vectors, 2 x 4 of them)
+    const f32x2 scale2 = {p.scale, p.scale};
 #pragma unroll
-    for (int ih = 0; ih < 8 / RB; ++ih) {
-      uint4 rw[RB][2];         // bf16: [row][pair] 16 bytes
-      f32x4 rf[RB][4];         // f32:  [row][tile]
+    for (int ih = 0; ih < 2; ++ih) {
+      u32x4_t rw[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) rw[i][q] = u32x4_t{0u, 0u, 0u, 0u};
       if (has_r) {
-        if constexpr (WIDE) {
-          if (wide) {
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-              for (int q = 0; q < 2; ++q) {
-                const int n = min(n0 + wn * 64 + (2 * q + (fk & 1)) * 16 + (fk >> 1) * 8, Cout - 8);
-                rw[i][q] = *reinterpret_cast<const uint4*>(reinterpret_cast<const TO*>(p.res) + (pix0 + (int64_t)(ih * RB + i) * W) * Cout + n);
-              }
-          } else {
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                const int n = min(n0 + wn * 64 + j * 16 + fk * 4, Cout - 4);
-                const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const TO*>(p.res) + (pix0 + (int64_t)(ih * RB + i) * W) * Cout + n);
-                if (j & 1) { rw[i][j >> 1].z = t.x; rw[i][j >> 1].w = t.y; } else { rw[i][j >> 1].x = t.x; rw[i][j >> 1].y = t.y; }
-              }
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < RB; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int n = min(n0 + wn * 64 + j * 16 + fk * 4, Cout - 4);
-              rf[i][j] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + (pix0 + (int64_t)(ih * RB + i) * W) * Cout + n);
-            }
-        }
+          for (int q = 0; q < 2; ++q)
+            rw[i][q] = __builtin_amdgcn_raw_buffer_load_b128(rr, voff + q * 64, (ih * 4 + i) * rowB, 0);
       }
 #pragma unroll
-      for (int i = 0; i < RB; ++i) {
-        const int ii = ih * RB + i;
-        const int64_t m = pix0 + (int64_t)ii * W;
-        uint2 pk[4];           // bf16 output: the 4 packed channels of tile j
+      for (int i = 0; i < 4; ++i) {
+        const int ii = ih * 4 + i;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          // residual of tiles 2q, 2q+1 in this lane's accumulator layout
-          float r0[4] = {0.f, 0.f, 0.f, 0.f}, r1[4] = {0.f, 0.f, 0.f, 0.f};
-          if (has_r) {
-            if constexpr (WIDE) {
-              uint2 ta, tb;
-              if (wide) {
-                const auto s0 = __builtin_amdgcn_permlane16_swap(rw[i][q].x, rw[i][q].z, false, false);
-                const auto s1 = __builtin_amdgcn_permlane16_swap(rw[i][q].y, rw[i][q].w, false, false);
-                ta = uint2{s0[0], s1[0]}; tb = uint2{s0[1], s1[1]};
-              } else {
-                ta = uint2{rw[i][q].x, rw[i][q].y}; tb = uint2{rw[i][q].z, rw[i][q].w};
-              }
-              const typename V16<TO>::x4 ea = *reinterpret_cast<const typename V16<TO>::x4*>(&ta), eb = *reinterpret_cast<const typename V16<TO>::x4*>(&tb);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { r0[r] = (float)ea[r]; r1[r] = (float)eb[r]; }
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) { r0[r] = rf[i][2 * q][r]; r1[r] = rf[i][2 * q + 1][r]; }
-            }
-          }
+          const auto x0_ = __builtin_amdgcn_permlane16_swap(rw[i][q][0], rw[i][q][2], false, false);
+          const auto x1_ = __builtin_amdgcn_permlane16_swap(rw[i][q][1], rw[i][q][3], false, false);
+          const uint2 ta = {x0_[0], x1_[0]}, tb = {x0_[1], x1_[1]};
+          const X4 ea = *reinterpret_cast<const X4*>(&ta), eb = *reinterpret_cast<const X4*>(&tb);
+          uint2 pk[2];
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int j = 2 * q + h;
-            const int n = n0 + wn * 64 + j * 16 + fk * 4;
-            float v[4] = {acc[j][ii][0], acc[j][ii][1], acc[j][ii][2], acc[j][ii][3]};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (has_b) v[r] += cb[j][r];
-              if (has_t) v[r] += ct[j][r];
-              if (has_r) v[r] += h == 0 ? r0[r] : r1[r];
-              v[r] *= scale;
-            }
-            if constexpr (WIDE) {
-              typename V16<TO>::x4 t = {(TO)v[0], (TO)v[1], (TO)v[2], (TO)v[3]};
-              pk[j] = *reinterpret_cast<uint2*>(&t);
-#pragma unroll
-              for (int r = 0; r < 4; ++r) v[r] = (float)t[r];            // statistics are those of the STORED tensor
-              if (!wide && n < Cout) *reinterpret_cast<uint2*>(reinterpret_cast<TO*>(p.out) + m * Cout + n) = pk[j];
-            } else {
-              if (n < Cout) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + m * Cout + n) = f32x4{v[0], v[1], v[2], v[3]};
-            }
-            if (do_stat && n < Cout) {
-              a1[j] += (v[0] + v[1]) + (v[2] + v[3]);
-              a2[j] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
-            }
+            const X4 e = h == 0 ? ea : eb;
+            f32x2 lo = {acc[j][ii][0], acc[j][ii][1]}, hi = {acc[j][ii][2], acc[j][ii][3]};
+            lo += cl[j]; hi += ch[j];
+            lo += f32x2{(float)e[0], (float)e[1]}; hi += f32x2{(float)e[2], (float)e[3]};
+            lo *= scale2; hi *= scale2;
+            const X4 t = {(TO)lo[0], (TO)lo[1], (TO)hi[0], (TO)hi[1]};
+            pk[h] = *reinterpret_cast<const uint2*>(&t);
+            // statistics are those of the STORED (rounded) tensor
+            const f32x2 bl = {(float)t[0], (float)t[1]}, bh = {(float)t[2], (float)t[3]};
+            s1[j] += bl + bh;
+            s2[j] += bl * bl + bh * bh;
           }
-          if constexpr (WIDE) {
-            if (wide) {
-              const auto s0 = __builtin_amdgcn_permlane16_swap(pk[2 * q].x, pk[2 * q + 1].x, false, false);
-              const auto s1 = __builtin_amdgcn_permlane16_swap(pk[2 * q].y, pk[2 * q + 1].y, false, false);
-              const int n = n0 + wn * 64 + (2 * q + (fk & 1)) * 16 + (fk >> 1) * 8;
-              if (n < Cout)
-                *reinterpret_cast<uint4*>(reinterpret_cast<TO*>(p.out) + m * Cout + n) = uint4{s0[0], s1[0], s0[1], s1[1]};
-            }
-          }
+          const auto y0_ = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
+          const auto y1_ = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
+          if (q == 0 ? okq0 : okq1)
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{y0_[0], y1_[0], y0_[1], y1_[1]}, ro, voff + q * 64, ii * rowB, 0);
         }
       }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a1[j] = s1[j][0] + s1[j][1]; a2[j] = s2[j][0] + s2[j][1]; }
   }
   RSTAMP(21, 0);
   if (do_stat) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fk * 4;
+      const int n = n0 + wn * 64 + j * 16 + fk_e * 4;
       const float r1 = row16_sum(a1[j]), r2 = row16_sum(a2[j]);
-      if (frow == 0 && n < Cout) {
+      if (frow_e == 0 && n < Cout) {
         atomicAdd(&s_stat[((n - n0) / scpg) * 2], (double)r1);
         atomicAdd(&s_stat[((n - n0) / scpg) * 2 + 1], (double)r2);
       }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+  }
+  // tile boundary: the producers have put the next tile's first patch and weight tile 0 into LDS; every wave's
+  // statistics are in s_stat
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  if (do_stat) {
     const int g0 = n0 / scpg;
     const int ng = min(p.stat_G - g0, (128 + scpg - 1) / scpg);
-    for (int i = tid; i < ng * 2; i += 256) {
-      const int k = i & 1, g = g0 + (i >> 1);
+    if (tid < ng * 2) {
+      const int k = tid & 1, g = g0 + (tid >> 1);
       atomicAdd(p.stat_out + (((int64_t)b * p.stat_nsplit + tile % p.stat_nsplit) * p.stat_G + g) * 2 + k,
                 s_stat[(g - g0) * 2 + k]);
+      s_stat[(g - g0) * 2 + k] = 0.0;           // for the next tile (its atomics come a whole tile later)
     }
   }
+  }     // tiles
+  __builtin_amdgcn_s_setprio(0);
   RSTAMP(22, 0);
   RSTAMP_RT(31, 0);
 }
@@ -743,8 +805,8 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
 template <typename T, typename TO, bool GNP>
 static int launch_ring(const ConvParams& p, hipStream_t st) {
   using namespace ring;
-  constexpr int SMEM_MAX = GOFF + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 8 + 64 * 4;
-  const int SMEM = GOFF + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0) + 64 * 8 + 64 * 4;
+  constexpr int SMEM_MAX = GOFF + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 8 + 64 * 4 + 128 * 4;
+  const int SMEM = GOFF + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0) + 64 * 8 + 64 * 4 + 128 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_ring_kernel<T, TO, GNP>),
@@ -756,13 +818,21 @@ static int launch_ring(const ConvParams& p, hipStream_t st) {
     attr_set = true;
   }
   const int tiles_x = p.W / 16, tiles_y = p.H / 16;
-  dim3 grid((unsigned)(p.B * tiles_x * tiles_y), (unsigned)((p.Cout + 127) / 128));
+  const int tpi = tiles_x * tiles_y, ny = (p.Cout + 127) / 128;
+  // workgroups per image: enough to put one on every CU (256), each then walks tpi / wpi tiles of its image; a layer
+  // of a single channel chunk is not walked (its patch pipeline would reach two tiles ahead)
+  int wpi = (256 + p.B * ny - 1) / (p.B * ny);
+  if (wpi > tpi) wpi = tpi;
+  if (wpi < 1) wpi = 1;
+  if (p.nk <= 9) wpi = tpi;
+  { static const char* e = getenv("FDBM_RING_WGS_PER_IMAGE"); if (e && atoi(e) > 0) wpi = atoi(e) < tpi ? atoi(e) : tpi; }   // experiments / tests
+  dim3 grid((unsigned)(p.B * wpi), (unsigned)ny);
 #ifdef FDBM_STAMPS
   ConvParams pd = p;
   { const char* e = getenv("FDBM_RING_DBG"); pd.ksplit = e ? atoi(e) : 0; }
-  conv_ring_kernel<T, TO, GNP><<<grid, 512, SMEM, st>>>(pd, tiles_x, tiles_y);
+  conv_ring_kernel<T, TO, GNP><<<grid, 512, SMEM, st>>>(pd, tiles_x, tiles_y, wpi);
 #else
-  conv_ring_kernel<T, TO, GNP><<<grid, 512, SMEM, st>>>(p, tiles_x, tiles_y);
+  conv_ring_kernel<T, TO, GNP><<<grid, 512, SMEM, st>>>(p, tiles_x, tiles_y, wpi);
 #endif
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm(ring)");
   return 0;
@@ -771,6 +841,8 @@ static int launch_ring(const ConvParams& p, hipStream_t st) {
 // Can this conv run on the ring kernel?  (shape / segment layout only; the caller checks the dtype)
 bool fdbm_conv_ring_ok(const ConvParams& p) {
   if (p.H % 16 || p.W % 16 || p.nseg < 1 || p.seg[0].taps != 9) return false;
+  // the one epilogue of the kernel: 16-byte stores of 8 channels, no pyramid / Combine extras, 32-bit offsets per image
+  if ((p.Cout & 7) || p.res_lo || p.comb_pyr || (int64_t)p.H * p.W * p.Cout * 2 >= (int64_t)1 << 31) return false;
   bool seen1 = false;
   for (int s = 0; s < p.nseg; ++s) {
     if (p.seg[s].taps == 1) {
@@ -788,12 +860,8 @@ int fdbm_launch_conv_ring(const ConvParams& p, int dt_in, int dt_out, hipStream_
   const bool gnp = p.gn_sums != nullptr;
   if (dt_in == FDBM_BF16 && dt_out == FDBM_BF16)
     return gnp ? launch_ring<bf16_t, bf16_t, true>(p, st) : launch_ring<bf16_t, bf16_t, false>(p, st);
-  if (dt_in == FDBM_BF16 && dt_out == FDBM_F32)
-    return gnp ? launch_ring<bf16_t, float, true>(p, st) : launch_ring<bf16_t, float, false>(p, st);
   if (dt_in == FDBM_F16 && dt_out == FDBM_F16)
     return gnp ? launch_ring<f16_t, f16_t, true>(p, st) : launch_ring<f16_t, f16_t, false>(p, st);
-  if (dt_in == FDBM_F16 && dt_out == FDBM_F32)
-    return gnp ? launch_ring<f16_t, float, true>(p, st) : launch_ring<f16_t, float, false>(p, st);
   fdbm_set_error("fdbm_conv_igemm(ring): unsupported dtypes %d -> %d", dt_in, dt_out);
   return 1;
 }

@@ -75,6 +75,12 @@ def check():
         dict(B=4, H=64, W=64, cins=[256, 128], cout=256, gn=True, stat=True, res=True),
         dict(B=2, H=128, W=128, cins=[96], cout=192, short=[96], gn=True),
         dict(B=1, H=256, W=256, cins=[128], cout=128, out_f32=True, res=True),
+        # several tiles per (persistent) workgroup: 2 per workgroup, with and without a 1-tap tail, 2 output blocks
+        dict(B=8, H=128, W=128, cins=[128], cout=128, gn=True, stat=True, res=True, tbias=True),
+        dict(B=2, H=256, W=256, cins=[128], cout=128, short=[128], gn=True, stat=True, res=True),
+        dict(B=16, H=64, W=64, cins=[256, 256], cout=256, gn=True, stat=True),
+        dict(B=8, H=128, W=128, cins=[128], cout=128, short=[128, 64]),
+        dict(B=4, H=128, W=256, cins=[192], cout=128, gn=True, stat=True, short=[64]),
     ]
     for kw in cases:
         res = {}

@@ -39,7 +39,10 @@ def run(B, cins, short, **feat):
             print("     t=%d " % t + " ".join(f"{(s[64 + 4 * t + k] - t0) * ns:8.0f}" for k in range(4)))
 
 
-if len(sys.argv) > 1:
+if len(sys.argv) > 1 and sys.argv[1] == "b4":
+    run(4, [256], [], gn=True)
+    run(4, [128], [], gn=True, stat=True, res=True)
+elif len(sys.argv) > 1:
     run(1, [256], [], gn=True)
 else:
     run(1, [128], [])

@@ -196,13 +196,15 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
 #ifdef RING_X_NOWEIGHTS
       return;
 #endif
-      // (the tile's last interval does neither: weights(nsteps) is the next tile's k-step 0, it stays in its set until
-      // the tile boundary puts it into slot 0)
-      if (s + 1 < nsteps) {
-        if constexpr (sl == 0) { RING_WRITE_W(wa0, wa1, wa2, wa3, 0); RING_LOAD_W(wa0, wa1, wa2, wa3); }
-        else if constexpr (sl == 1) { RING_WRITE_W(wb0_, wb1_, wb2_, wb3_, 1); RING_LOAD_W(wb0_, wb1_, wb2_, wb3_); }
-        else { RING_WRITE_W(wc0, wc1, wc2, wc3, 2); RING_LOAD_W(wc0, wc1, wc2, wc3); }
-      }
+      // UNCONDITIONAL, every interval the same four writes and four requests: with a guard around them hipcc can no
+      // longer count the requests in flight and waits for ALL of them (vmcnt(0)) before every write - the producers'
+      // interval then lasts a load latency.  Past the tile's last k-step the cursor has wrapped: the surplus request is
+      // the next tile's k-step (a workgroup walks several tiles only when the layer has 9-tap chunks alone, so
+      // nsteps % 3 == 0 and k-step 0 of the next tile lands in slot 0 by itself); behind the last tile it is never read.
+      (void)s;
+      if constexpr (sl == 0) { RING_WRITE_W(wa0, wa1, wa2, wa3, 0); RING_LOAD_W(wa0, wa1, wa2, wa3); }
+      else if constexpr (sl == 1) { RING_WRITE_W(wb0_, wb1_, wb2_, wb3_, 1); RING_LOAD_W(wb0_, wb1_, wb2_, wb3_); }
+      else { RING_WRITE_W(wc0, wc1, wc2, wc3, 2); RING_LOAD_W(wc0, wc1, wc2, wc3); }
     };
 
     // weights 0..2 are requested FIRST: their latency (the launch's first touch of the layer's weights) passes behind
@@ -219,7 +221,11 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
     // scratch memory)
     auto ppix_of = [&](int j, int ti) __attribute__((always_inline)) {
       const int ty_ = ti / tiles_x, tx_ = ti - ty_ * tiles_x;
-      const int row = (ptid >> 3) + 32 * j;
+      // (the lane index made opaque per call site: the tile-independent halves of these expressions, 22 values, were
+      // otherwise hoisted out of the tile loop, spilled, and reloaded behind a vmcnt(0) each)
+      int ptid_o = ptid;
+      asm volatile("" : "+v"(ptid_o));
+      const int row = (ptid_o >> 3) + 32 * j;
       const int rr = min(row, PROWS - 1);
       const int pr = rr / PC, pc = rr - pr * PC;
       const int iy = ty_ * 16 + pr - 1, ix = tx_ * 16 + pc - 1;
@@ -362,7 +368,6 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       if (nc_ == seg_nch(s_)) { nc_ = 0; ns_ = s_ + 1; }
       if (ns_ == nseg) { ns_ = 0; wrapped = true; }
     };
-    const int wrot = nsteps % 3;
     for (int ti = tile0; ti < tiles_per_image; ti += wgs_per_image) {
       const bool last_tile = ti + wgs_per_image >= tiles_per_image;
       int cs = 0, cc = 0, sbase = 0;
@@ -480,50 +485,7 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       }
       // ---- tile boundary (the consumers are in the tile's second-to-last half / its epilogue) ---------------------------
       if (!last_tile) {
-        // weights: k-steps 0, 1, 2 of the next tile were requested by this tile's last intervals into the sets
-        // (nsteps + j) % 3; back to "k-step j in set j", k-step 0 into ring slot 0, k-step 3 requested
-        if (wrot == 1) {
-          uint4 t0 = wa0, t1 = wa1, t2 = wa2, t3 = wa3;
-          wa0 = wb0_; wa1 = wb1_; wa2 = wb2_; wa3 = wb3_;
-          wb0_ = wc0; wb1_ = wc1; wb2_ = wc2; wb3_ = wc3;
-          wc0 = t0; wc1 = t1; wc2 = t2; wc3 = t3;
-        } else if (wrot == 2) {
-          uint4 t0 = wa0, t1 = wa1, t2 = wa2, t3 = wa3;
-          wa0 = wc0; wa1 = wc1; wa2 = wc2; wa3 = wc3;
-          wc0 = wb0_; wc1 = wb1_; wc2 = wb2_; wc3 = wb3_;
-          wb0_ = t0; wb1_ = t1; wb2_ = t2; wb3_ = t3;
-        }
-        RING_WRITE_W(wa0, wa1, wa2, wa3, 0);
-        RING_LOAD_W(wa0, wa1, wa2, wa3);
-        if (n1 > 0) {
-          // behind a 1-tap tail the next tile's first patch is staged here, in one piece (the main pipeline's registers
-          // went to the tail's first patch): one exposed load + 11 items per tile of a layer with a shortcut segment
-          patch_request_begin(0, 0);
-          load_item(std::integral_constant<int, 0>{}, true); load_item(std::integral_constant<int, 1>{}, true); load_item(std::integral_constant<int, 2>{}, true);
-          load_item(std::integral_constant<int, 3>{}, true); load_item(std::integral_constant<int, 4>{}, true); load_item(std::integral_constant<int, 5>{}, true);
-          load_item(std::integral_constant<int, 6>{}, true); load_item(std::integral_constant<int, 7>{}, true); load_item(std::integral_constant<int, 8>{}, true);
-          load_item(std::integral_constant<int, 9>{}, true); load_item(std::integral_constant<int, 10>{}, true);
-          pcok = pcok_next;
-          const bool r0 = is_reg(0);
-          if (r0) load_scale_shift(0, 0);
-          xform_item(std::integral_constant<int, 0>{}, r0, true); xform_item(std::integral_constant<int, 1>{}, r0, true); xform_item(std::integral_constant<int, 2>{}, r0, true);
-          xform_item(std::integral_constant<int, 3>{}, r0, true); xform_item(std::integral_constant<int, 4>{}, r0, true); xform_item(std::integral_constant<int, 5>{}, r0, true);
-          xform_item(std::integral_constant<int, 6>{}, r0, true); xform_item(std::integral_constant<int, 7>{}, r0, true); xform_item(std::integral_constant<int, 8>{}, r0, true);
-          xform_item(std::integral_constant<int, 9>{}, r0, true); xform_item(std::integral_constant<int, 10>{}, r0, true);
-          write_item(std::integral_constant<int, 0>{}, pb); write_item(std::integral_constant<int, 1>{}, pb); write_item(std::integral_constant<int, 2>{}, pb);
-          write_item(std::integral_constant<int, 3>{}, pb); write_item(std::integral_constant<int, 4>{}, pb); write_item(std::integral_constant<int, 5>{}, pb);
-          write_item(std::integral_constant<int, 6>{}, pb); write_item(std::integral_constant<int, 7>{}, pb); write_item(std::integral_constant<int, 8>{}, pb);
-          write_item(std::integral_constant<int, 9>{}, pb); write_item(std::integral_constant<int, 10>{}, pb);
-          // and the patch of its chunk 1 requested (clamped to chunk 0 where the layer has a single chunk)
-          int s1 = 0, c1 = 1;
-          if (c1 == sg_n0) { c1 = 0; s1 = 1; }
-          if (s1 >= nseg) { s1 = 0; c1 = 0; }
-          patch_request_begin(s1, c1);
-          load_item(std::integral_constant<int, 0>{}, true); load_item(std::integral_constant<int, 1>{}, true); load_item(std::integral_constant<int, 2>{}, true);
-          load_item(std::integral_constant<int, 3>{}, true); load_item(std::integral_constant<int, 4>{}, true); load_item(std::integral_constant<int, 5>{}, true);
-          load_item(std::integral_constant<int, 6>{}, true); load_item(std::integral_constant<int, 7>{}, true); load_item(std::integral_constant<int, 8>{}, true);
-          load_item(std::integral_constant<int, 9>{}, true); load_item(std::integral_constant<int, 10>{}, true);
-        }
+        // (weights: nothing to do - the ring runs on across the boundary, see weights_interval)
         // the next tile becomes the current one
         const int tn = ti + wgs_per_image;
 #pragma unroll
@@ -825,6 +787,10 @@ static int launch_ring(const ConvParams& p, hipStream_t st) {
   if (wpi > tpi) wpi = tpi;
   if (wpi < 1) wpi = 1;
   if (p.nk <= 9) wpi = tpi;
+  // and so is a layer with 1-tap (shortcut) segments: the weight ring runs on across a tile boundary only when the tile's
+  // k-steps are a multiple of the ring's 3 slots, which 9-tap chunks alone guarantee
+  for (int sg = 0; sg < p.nseg; ++sg)
+    if (p.seg[sg].taps == 1) wpi = tpi;
   { static const char* e = getenv("FDBM_RING_WGS_PER_IMAGE"); if (e && atoi(e) > 0) wpi = atoi(e) < tpi ? atoi(e) : tpi; }   // experiments / tests
   dim3 grid((unsigned)(p.B * wpi), (unsigned)ny);
 #ifdef FDBM_STAMPS

@@ -1,11 +1,11 @@
 """Per-kernel-family averages of rocprofv3 --pmc SQ counters (one directory per pass) -> table.
    python tools/pmc_sq_summarize.py DIR [DIR ...]"""
 import csv, glob, sys, collections, re
-FAMS = ("conv_patch_kernel", "conv_tap_kernel", "resample2x_tile_kernel", "resample2x_kernel", "attention_mfma256_kernel",
+FAMS = ("conv_ring_kernel", "conv_patch_kernel", "conv_tap_kernel", "resample2x_tile_kernel", "resample2x_kernel", "attention_mfma256_kernel",
         "conv_stem_mfma_kernel", "dense_rows_kernel")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:
-    for f in glob.glob(d + "/*/*counter_collection.csv"):
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             fam = next((x for x in FAMS if x in k), None)

@@ -251,9 +251,10 @@ int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int first_taps, int
                       int* bm, int* bn, int* ksplit);
 /* kernel-selection policy used by fdbm_conv_plan_ex / fdbm_conv_igemm: bit 0 allows kind 1, bit 1
  * allows kind 2, bit 2 turns on k-groups inside the kind-0 kernel, bit 3 lets the producer / consumer
- * ring kernel (csrc/conv_ring.hip: bf16 input, 16 x 16 pixel tiles, >= 200 tiles) take the place of
- * kind 1; mask < 0 only queries.  Returns the previous mask (default 11).  Results are the same
- * convolution under every policy. */
+ * ring kernel (csrc/conv_ring_impl.h: 16-bit tensors; 16 x 16 pixel tiles when the launch has >= 200 of them,
+ * else 8 x 16 pixel tiles when it has >= 128 of those) take the place of kinds 1 and 2, bit 4 makes it use
+ * 8 x 16 pixel tiles wherever they fit (tests); mask < 0 only queries.  Returns the previous mask
+ * (default 11).  Results are the same convolution under every policy. */
 int fdbm_conv_policy(int mask);
 /* kernel family of the most recent fdbm_conv_igemm launch of this process: 0 tap-outer implicit GEMM,
  * 1 halo-patch, 2 wave-per-tap, 3 ring; -1 before the first call (for measurement harnesses) */

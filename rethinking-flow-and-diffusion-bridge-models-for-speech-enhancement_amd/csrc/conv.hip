@@ -516,7 +516,7 @@ extern "C" int fdbm_conv_last_kind(void) { return g_last_kind; }
 
 extern "C" int fdbm_conv_policy(int mask) {
   const int old = conv_policy();
-  if (mask >= 0) g_policy = mask & 15;
+  if (mask >= 0) g_policy = mask & 31;
   return old;
 }
 
@@ -552,7 +552,8 @@ extern "C" int fdbm_conv_plan(int64_t M, int Cout, int nk, int* bm, int* bn, int
 int fdbm_launch_conv_patch(const ConvParams& p, int dt_in, int dt_out, int th, hipStream_t st);   // conv_patch.hip
 int fdbm_launch_conv_tap(const ConvParams& p, int dt_in, int dt_out, int tw, int nt, hipStream_t st);   // conv_tap.hip
 int fdbm_launch_conv_ring(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                  // conv_ring.hip
-bool fdbm_conv_ring_ok(const ConvParams& p);
+bool fdbm_conv_ring_ok(const ConvParams& p, int rows);
+int fdbm_launch_conv_ring8(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                 // conv_ring8.hip
 
 // Which kernel runs a conv of this shape: kind 1 = halo-patch 3x3 kernel (conv_patch.hip, tile
 // th x 16 pixels x 128 channels), kind 2 = wave-per-tap 3x3 kernel for small grids (conv_tap.hip,
@@ -699,12 +700,23 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     p.stat_out = a->stat_out; p.stat_G = a->stat_G; p.stat_nsplit = a->stat_nsplit;
   }
   hipStream_t st = (hipStream_t)stream;
-  if ((conv_policy() & 8) && (conv_policy() & 1) && a->dt_in != FDBM_F32 && a->dt_out == a->dt_in && fdbm_conv_ring_ok(p)) {
+  if ((conv_policy() & 8) && (conv_policy() & 1) && a->dt_in != FDBM_F32 && a->dt_out == a->dt_in) {
     // producer / consumer ring kernel: one 512-thread workgroup per CU on a 16 x 16 pixel x 128 channel tile; wants
-    // (nearly) a tile per CU, below that the halo-patch kernel's 8-row tiles fill the chip better
-    static const char* rmin = getenv("FDBM_RING_MIN_TILES");   // experiments
-    const int64_t tiles = (int64_t)a->B * (a->H / 16) * (a->W / 16) * ((a->Cout + 127) / 128);
-    if (tiles >= (rmin ? atoi(rmin) : 200)) { g_last_kind = 3; return fdbm_launch_conv_ring(p, a->dt_in, a->dt_out, st); }
+    // (nearly) a tile per CU.  Below that the same kernel on 8 x 16 pixel tiles: twice the workgroups, half the serial
+    // work in each (these launches are latency-bound); below THAT the wave-per-tap kernel's small tiles fill the chip better.
+    // (policy bit 16: 8-row tiles wherever they fit - tests)
+    static const char* rmin = getenv("FDBM_RING_MIN_TILES");    // experiments
+    static const char* rmin8 = getenv("FDBM_RING8_MIN_TILES");
+    const int64_t nb = (int64_t)a->B * (a->W / 16) * ((a->Cout + 127) / 128);
+    const bool force8 = (conv_policy() & 16) != 0;
+    if (!force8 && fdbm_conv_ring_ok(p, 16) && nb * (a->H / 16) >= (rmin ? atoi(rmin) : 200)) {
+      g_last_kind = 3;
+      return fdbm_launch_conv_ring(p, a->dt_in, a->dt_out, st);
+    }
+    if (fdbm_conv_ring_ok(p, 8) && (force8 || nb * (a->H / 8) >= (rmin8 ? atoi(rmin8) : 128))) {
+      g_last_kind = 3;
+      return fdbm_launch_conv_ring8(p, a->dt_in, a->dt_out, st);
+    }
   }
   g_last_kind = kind;
   if (kind == 1) {

@@ -5,6 +5,7 @@ next to each check: bit-exact for the sampler update; fp32 kernels within a few 
 of the fp32 reference; bf16 kernels within bf16 rounding of inputs/outputs.
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -347,10 +348,12 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=[3, 0], ids=["auto", "tapouter"])
+@pytest.fixture(params=[3, 0, 11, 27], ids=["auto", "tapouter", "ring", "ring8"])
 def conv_kernels(request):
-    """Every conv case runs under the default kernel selection (halo-patch / wave-per-tap / tap-outer by
-    shape) and with the tap-outer implicit GEMM forced."""
+    """Every conv case runs under the kernel selection without the ring kernel (halo-patch / wave-per-tap / tap-outer by
+    shape), with the tap-outer implicit GEMM forced, under the default policy (producer / consumer ring kernel where it
+    applies: 16-bit tensors, >= 200 tiles of 16 x 16 pixels, or >= 128 of 8 x 16) and with the ring kernel's 8-row tiles
+    wherever they fit."""
     old = hip.conv_policy(request.param)
     yield request.param
     hip.conv_policy(old)
@@ -654,3 +657,20 @@ def test_waveform_normalisation_fused(golden, normalize, clip, gain):
     assert abs(nf2[1].item() - ofe.norm_factor(0.5 * wave.flip(-1), normalize).item()) <= 2e-7 * nf2[1].item()
     x2 = fe.to_audio(fe.spec_forward_padded(w2, "reflection", norm=nf2)[:, 0], w2.shape[-1], norm=nf2, clip=clip).cpu()
     assert (x2[0] - x[0]).abs().max() < 2e-5 * max(1.0, gain)
+
+
+@pytest.mark.gpu
+def test_conv_ring_kernel_cases():
+    """The producer / consumer ring kernel (16- and 8-row tiles, several tiles per workgroup, shortcut segments, GroupNorm
+    prologue, statistics / residual / time-bias epilogue) against a torch fp32 conv on the same device-rounded inputs;
+    every case asserts that the ring kernel is the one that ran (fdbm_conv_last_kind)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "ring_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "ring_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    old = hip.conv_policy(-1)
+    try:
+        mod.check()
+    finally:
+        hip.conv_policy(old)

@@ -73,8 +73,7 @@ def check():
         dict(B=1, H=256, W=256, cins=[128], cout=128, short=[128, 128], gn=True, stat=True),
         dict(B=2, H=128, W=256, cins=[256], cout=256, short=[256], gn=True, res=False),
         dict(B=4, H=64, W=64, cins=[256, 128], cout=256, gn=True, stat=True, res=True),
-        dict(B=2, H=128, W=128, cins=[96], cout=192, short=[96], gn=True),
-        dict(B=1, H=256, W=256, cins=[128], cout=128, out_f32=True, res=True),
+        dict(B=2, H=128, W=128, cins=[96], cout=256, short=[96], gn=True),
         # several tiles per (persistent) workgroup: 2 per workgroup, with and without a 1-tap tail, 2 output blocks
         dict(B=8, H=128, W=128, cins=[128], cout=128, gn=True, stat=True, res=True, tbias=True),
         dict(B=2, H=256, W=256, cins=[128], cout=128, short=[128], gn=True, stat=True, res=True),
@@ -82,9 +81,22 @@ def check():
         dict(B=8, H=128, W=128, cins=[128], cout=128, short=[128, 64]),
         dict(B=4, H=128, W=256, cins=[192], cout=128, gn=True, stat=True, short=[64]),
     ]
-    for kw in cases:
+    # 8 x 16 pixel tiles (policy bit 16): the maps below a tile per CU, and the shapes above again
+    cases8 = [
+        dict(B=1, H=128, W=128, cins=[128], cout=128, gn=True, stat=True, res=True, tbias=True),
+        dict(B=1, H=128, W=128, cins=[128, 128], cout=128, gn=True, stat=True),
+        dict(B=1, H=128, W=128, cins=[128], cout=128, short=[128, 128], gn=True, stat=True, res=True),
+        dict(B=1, H=64, W=64, cins=[256], cout=256, gn=True, stat=True, res=True, tbias=True),
+        dict(B=1, H=64, W=64, cins=[256], cout=256, short=[256, 128], gn=True, stat=True),
+        dict(B=1, H=64, W=64, cins=[128], cout=256, short=[128], gn=True),
+        dict(B=1, H=8, W=16, cins=[64], cout=128),
+        dict(B=3, H=24, W=32, cins=[96], cout=256, short=[96], gn=True, stat=True, res=True),
+        dict(B=8, H=128, W=128, cins=[128], cout=128, gn=True, stat=True, res=True, tbias=True),
+        dict(B=4, H=64, W=64, cins=[256, 256], cout=256, gn=True, stat=True),
+    ]
+    for kw, ringpol in [(c, 11) for c in cases] + [(c, 27) for c in cases8]:
         res = {}
-        for pol in (3, 11):
+        for pol in (3, ringpol):
             hip.conv_policy(pol)
             ca, out, ref, st, keep = make(**kw)
             hip.call("fdbm_conv_igemm", ca)
@@ -96,9 +108,12 @@ def check():
                 exp = torch.stack([o.sum((1, 3)), (o * o).sum((1, 3))], -1).double()
                 serr = ((st.sum(1) - exp).abs() / (exp.abs() + 1.0)).max().item()
             res[pol] = (err, serr, out.float().clone())
-        d = (res[3][2] - res[11][2]).abs().max().item()
-        print(f"{kw}: patch err {res[3][0]:.3e} stat {res[3][1]:.1e} | ring err {res[11][0]:.3e} stat {res[11][1]:.1e} | ring vs patch {d:.3e}", flush=True)
-        assert res[11][0] < 3e-2 and res[11][1] < 1e-5 and not math.isnan(res[11][0]), "ring kernel mismatch"
+            res[pol] += (hip.lib().fdbm_conv_last_kind(),)
+        r = res[ringpol]
+        d = (res[3][2] - r[2]).abs().max().item()
+        print(f"{kw}: patch err {res[3][0]:.3e} stat {res[3][1]:.1e} | ring{'8' if ringpol & 16 else ''} (kind {r[3]}) err {r[0]:.3e} stat {r[1]:.1e} | ring vs patch {d:.3e}", flush=True)
+        assert r[3] == 3, "the ring kernel did not take this case"
+        assert r[0] < 3e-2 and r[1] < 1e-5 and not math.isnan(r[0]), "ring kernel mismatch"
     hip.conv_policy(11)
 
 
@@ -122,6 +137,27 @@ def bench(reps=30):
                     fl = 2.0 * B * 256 * 256 * 128 * (9 * sum(cins) + sum(short))
                     line += f"  {'patch' if pol == 3 else 'ring'} {us:6.1f} us {fl / us / 1e6:6.1f} TF/s"
                 print(line, flush=True)
+    # the maps below a tile per CU at batch 1: default policy without the ring kernel (3), ring on 16-row tiles forced by
+    # FDBM_RING_MIN_TILES=1 in the environment if wanted, and 8-row tiles (27)
+    for H, cins, cout, short in ((128, [128], 128, []), (128, [128, 128], 128, []), (128, [128], 128, [128, 128]),
+                                 (64, [256], 256, []), (64, [256, 256], 256, []), (64, [256], 256, [256, 128]), (64, [128], 128, []),
+                                 (32, [256], 256, []), (32, [256, 256], 256, [])):
+        feat = dict(gn=True, stat=True, res=True)
+        line = f"B1 {H}x{H} {cins}+{short}->{cout}:"
+        for pol in (3, 27):
+            hip.conv_policy(pol)
+            ca, out, ref, st, keep = make(1, H, H, cins, cout, short=short, **feat)
+            for _ in range(5):
+                hip.call("fdbm_conv_igemm", ca)
+            torch.cuda.synchronize()
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                hip.call("fdbm_conv_igemm", ca)
+            b_.record(); torch.cuda.synchronize()
+            us = a.elapsed_time(b_) * 1e3 / reps
+            line += f"  {'tap/patch' if pol == 3 else 'ring8'} (kind {hip.lib().fdbm_conv_last_kind()}) {us:6.1f} us"
+        print(line, flush=True)
     hip.conv_policy(11)
 
 

@@ -316,7 +316,8 @@ def main():
     f_dom = sum(flops[i] for i in sel)
     achieved = f_dom / t_dom / 1e12
     traffic = None
-    fam_name = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel", 3: "conv_ring_kernel"}
+    fam_name = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel", 3: "conv_ring_kernel<R=16>",
+                4: "conv_ring_kernel<R=8>"}
     pmc = os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_b{args.batch}_bf16.json")
     if args.dtype == "bf16" and os.path.exists(pmc):
         try:        # measured offline with rocprofv3 --pmc (tools/pmc_workload.py), bytes per launch

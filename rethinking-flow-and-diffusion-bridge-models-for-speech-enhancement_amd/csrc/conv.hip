@@ -510,7 +510,8 @@ static int conv_policy() {
   }
   return g_policy;
 }
-// 0 = tap-outer implicit GEMM, 1 = halo-patch, 2 = wave-per-tap, 3 = producer/consumer ring; -1 before the first call.
+// 0 = tap-outer implicit GEMM, 1 = halo-patch, 2 = wave-per-tap, 3 = producer/consumer ring on 16 x 16 pixel tiles,
+// 4 = the same on 8 x 16 pixel tiles; -1 before the first call.
 // For measurement harnesses (bench.py prices each kernel family against its roofline).
 extern "C" int fdbm_conv_last_kind(void) { return g_last_kind; }
 
@@ -714,7 +715,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
       return fdbm_launch_conv_ring(p, a->dt_in, a->dt_out, st);
     }
     if (fdbm_conv_ring_ok(p, 8) && (force8 || nb * (a->H / 8) >= (rmin8 ? atoi(rmin8) : 128))) {
-      g_last_kind = 3;
+      g_last_kind = 4;
       return fdbm_launch_conv_ring8(p, a->dt_in, a->dt_out, st);
     }
   }

@@ -9,6 +9,8 @@ for d in sys.argv[1:]:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"]
             fam = next((x for x in FAMS if x in k), None)
+            if fam == "conv_ring_kernel":
+                fam += "<R=8>" if ("Li8EE" in k or ", 8>" in k) else "<R=16>"
             if fam == "conv_tap_kernel":
                 m = re.search(r"Li(\d+)ELi(\d+)ELi(\d+)ELb([01])", k)
                 if m:

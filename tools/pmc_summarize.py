@@ -12,6 +12,8 @@ for name, d in (("FETCH_SIZE", sys.argv[1]), ("WRITE_SIZE", sys.argv[2])):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
         fam = next((f_ for f_ in FAMILIES if f_ in k), None)
+        if fam == "conv_ring_kernel":        # two tile heights (last template argument): separate kernels
+            fam += "<R=8>" if ("Li8EE" in k or ", 8>" in k) else "<R=16>"
         if fam and r["Counter_Name"] == name:
             acc[fam].append(float(r["Counter_Value"]))
     for fam, v in acc.items():

@@ -11,9 +11,9 @@ from ring_check import make
 DEV = "cuda:0"
 
 
-def run(B, cins, short, **feat):
-    hip.conv_policy(11)
-    ca, out, ref, st, keep = make(B, 256, 256, cins, 128, short=short, **feat)
+def run(B, cins, short, H=256, pol=11, cout=128, **feat):
+    hip.conv_policy(pol)
+    ca, out, ref, st, keep = make(B, H, H, cins, cout, short=short, **feat)
     ws = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
     ca.workspace, ca.workspace_bytes = ws.data_ptr(), ws.numel()
     for _ in range(5):
@@ -24,7 +24,7 @@ def run(B, cins, short, **feat):
     s = ws.view(torch.int64)[:128].cpu().tolist()
     t0 = min(s[0], s[32])
     ns = (s[31] - s[30]) * 10.0 / max(1, s[22] - s[0])
-    print(f"B{B} {cins}+{short} {feat}: launch {a.elapsed_time(b_) * 1e3:.1f} us, shader clock {1e3 / ns:.0f} MHz")
+    print(f"B{B} {H}x{H} {cins}+{short}->{cout} {feat} policy {pol}: launch {a.elapsed_time(b_) * 1e3:.1f} us, shader clock {1e3 / ns:.0f} MHz")
     cn = {0: "start", 1: "setup done", 2: "gn table", 3: "tick(-1) passed", 20: "k-loop done", 21: "stores issued", 22: "end"}
     for i in list(range(0, 20)) + [20, 21, 22]:
         if s[i]:
@@ -42,6 +42,10 @@ def run(B, cins, short, **feat):
 if len(sys.argv) > 1 and sys.argv[1] == "b4":
     run(4, [256], [], gn=True)
     run(4, [128], [], gn=True, stat=True, res=True)
+elif len(sys.argv) > 1 and sys.argv[1] == "r8":
+    run(1, [128], [], H=128, pol=27, gn=True, stat=True, res=True)
+    run(1, [128, 128], [], H=128, pol=27, gn=True, stat=True, res=True)
+    run(1, [256], [], H=64, pol=27, cout=256, gn=True, stat=True, res=True)
 elif len(sys.argv) > 1:
     run(1, [256], [], gn=True)
 else:

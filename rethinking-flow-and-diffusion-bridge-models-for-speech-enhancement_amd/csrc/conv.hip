@@ -591,9 +591,10 @@ extern "C" int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int firs
       }
     }
   }
-  // a conv with <= 16 output channels (the 4-channel heads) would spend 128 channels' worth of MFMAs in the
-  // halo-patch kernel: where the wave-per-tap grid is allowed, its 16-channel tile does the same work
-  if (patch_ok && !(Cout <= 16 && tap_nt)) {
+  // (a conv with <= 16 output channels and f32 output - the 4-channel heads - runs the halo-patch kernel on 16-channel
+  // tiles: fdbm_launch_conv_patch)
+  static const char* headtap = getenv("FDBM_HEAD_TAP");          // experiments: "1" = the previous choice
+  if (patch_ok && !(Cout <= 16 && tap_nt && headtap && headtap[0] == '1')) {
     *kind = 1;
     *th = (H % 16 == 0 && tiles16 >= 256) ? 16 : 8;
     return 0;

@@ -21,18 +21,19 @@
 #include "conv_common.h"
 
 template <typename T, typename TO, int TH, int BN, bool GNP>
-__global__ void __launch_bounds__(64 * (TH / 4) * (BN / 64))
+__global__ void __launch_bounds__(64 * (TH / 4) * (BN >= 64 ? BN / 64 : 1))
 conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   constexpr int KC = 128 / (int)sizeof(T);
   constexpr int VW = 16 / (int)sizeof(T);
-  constexpr int WM = TH / 4, WN = BN / 64;
+  // (BN = 16: the 4-channel heads - one n-tile per wave instead of four, a sixteenth of the weight tile)
+  constexpr int WM = TH / 4, WN = BN >= 64 ? BN / 64 : 1;
   constexpr int NTHR = 64 * WM * WN;
-  constexpr int MT = 4, NT = 4;
+  constexpr int MT = 4, NT = BN >= 64 ? 4 : BN / 16;
   constexpr int PC = 18, PROWS = (TH + 2) * PC;
   constexpr int PBUF = PROWS * 128;
   constexpr int WBUF = BN * 128;
   constexpr int NPL = (PROWS * 8 + NTHR - 1) / NTHR;   // patch 16-byte items per thread
-  constexpr int NWL = BN * 8 / NTHR;                   // weight 16-byte items per thread
+  constexpr int NWL = (BN * 8 + NTHR - 1) / NTHR;      // weight 16-byte items per thread
   constexpr bool F32 = sizeof(T) == 4;
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -127,22 +128,26 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
     write_patch_item(std::integral_constant<int, 5>{}, buf);
     write_patch_item(std::integral_constant<int, 6>{}, buf);
     write_patch_item(std::integral_constant<int, 7>{}, buf);
+    write_patch_item(std::integral_constant<int, 8>{}, buf);
+    write_patch_item(std::integral_constant<int, 9>{}, buf);
+    write_patch_item(std::integral_constant<int, 10>{}, buf);
+    write_patch_item(std::integral_constant<int, 11>{}, buf);
   };
-  static_assert(NPL <= 8, "patch staging assumes at most 8 items per thread");
+  static_assert(NPL <= 12, "patch staging assumes at most 12 items per thread");
 
   // weight staging registers as four named scalars (an array here ends up in scratch memory)
   uint4 wr0 = {0u, 0u, 0u, 0u}, wr1 = wr0, wr2 = wr0, wr3 = wr0;
   static_assert(NWL <= 4, "weight staging assumes at most 4 items per thread");
 #define W_LOAD(J)                                                                              \
   if constexpr (NWL > J) {                                                                     \
-    const int q = tid + NTHR * J;                                                              \
+    const int q = min(tid + NTHR * J, BN * 8 - 1);                                             \
     wr##J = *reinterpret_cast<const uint4*>(wp + (int64_t)(q >> 3) * KC + (q & 7) * VW);       \
   }
 #define W_STORE(J)                                                                             \
   if constexpr (NWL > J) {                                                                     \
     const int q = tid + NTHR * J;                                                              \
     const int row = q >> 3, ch = q & 7;                                                        \
-    *reinterpret_cast<uint4*>(Wt + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = wr##J;       \
+    if (q < BN * 8) *reinterpret_cast<uint4*>(Wt + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = wr##J;       \
   }
   auto load_w = [&](int kidx) __attribute__((always_inline)) {
     const T* wp = reinterpret_cast<const T*>(p.w) + ((int64_t)kidx * p.CoutPad + n0) * KC;
@@ -169,8 +174,8 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
 #define A_BASE(DX, KK) ((wm * 4 * PC + frow + (DX)) * 128 + ((((KK) * 4 + fk) ^ (((frow + (DX)) >> 1) & 7)) << 4))
   const int ab00 = A_BASE(0, 0), ab01 = A_BASE(0, 1), ab10 = A_BASE(1, 0), ab11 = A_BASE(1, 1), ab20 = A_BASE(2, 0), ab21 = A_BASE(2, 1);
 #undef A_BASE
-  const int wb0 = (wn * 64 + frow) * 128 + (((0 * 4 + fk) ^ ((frow >> 1) & 7)) << 4);
-  const int wb1 = (wn * 64 + frow) * 128 + (((1 * 4 + fk) ^ ((frow >> 1) & 7)) << 4);
+  const int wb0 = (wn * (NT * 16) + frow) * 128 + (((0 * 4 + fk) ^ ((frow >> 1) & 7)) << 4);
+  const int wb1 = (wn * (NT * 16) + frow) * 128 + (((1 * 4 + fk) ^ ((frow >> 1) & 7)) << 4);
   // one half (kk = 0 | 1: 16 of the 32 k-values of a 128-byte row) of a k-step's MFMAs
   auto compute = [&](int pbuf, int wbuf, int dy, int dx, int kk) __attribute__((always_inline)) {
     const unsigned char* P = s_patch + pbuf * PBUF;
@@ -227,8 +232,9 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
     for (int j = 0; j < NWL; ++j) {
       const int q = tid + NTHR * j;
       const int row = q >> 3, ch = q & 7;
-      *reinterpret_cast<uint4*>(s_w + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) =
-          *reinterpret_cast<const uint4*>(wp + (int64_t)row * KC + ch * VW);
+      if (q < BN * 8)
+        *reinterpret_cast<uint4*>(s_w + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) =
+            *reinterpret_cast<const uint4*>(wp + (int64_t)row * KC + ch * VW);
     }
   }
   build_gn_table();
@@ -268,6 +274,12 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
         compute(pb, wb, dy, dx, 0);
         if constexpr (k >= 1) { if (!lo_half) write_patch_item(std::integral_constant<int, k - 1>{}, pb ^ 1); }
         compute(pb, wb, dy, dx, 1);
+        if constexpr (k == 8) {            // (the two-wave tiles of the 4-channel heads: up to 12 items per thread)
+          write_patch_item(std::integral_constant<int, 8>{}, pb ^ 1);
+          write_patch_item(std::integral_constant<int, 9>{}, pb ^ 1);
+          write_patch_item(std::integral_constant<int, 10>{}, pb ^ 1);
+          write_patch_item(std::integral_constant<int, 11>{}, pb ^ 1);
+        }
         if (ntaps != 9) write_patch(pb ^ 1);
         write_w(wb ^ 1);
         __syncthreads();
@@ -296,7 +308,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
     const int64_t m = img + (int64_t)y * W + x;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fk * 4;
+      const int n = n0 + wn * (NT * 16) + j * 16 + fk * 4;
       float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
       const bool live = n < Cout;
       if (live) conv_epilogue4<TO>(p, m, b, n, v);
@@ -309,7 +321,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   if (do_stat) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + fk * 4;
+      const int n = n0 + wn * (NT * 16) + j * 16 + fk * 4;
       const float r1 = row16_sum(a1[j]), r2 = row16_sum(a2[j]);
       if (frow == 0 && n < Cout) {
         atomicAdd(&s_stat[((n - n0) / scpg) * 2], (double)r1);
@@ -329,7 +341,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
 
 template <typename T, typename TO, int TH, int BN, bool GNP>
 static int launch_patch(const ConvParams& p, hipStream_t st) {
-  constexpr int NTHR = 64 * (TH / 4) * (BN / 64);
+  constexpr int NTHR = 64 * (TH / 4) * (BN >= 64 ? BN / 64 : 1);
   constexpr int SMEM_MAX = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 8 + 64 * 4;
   // the GroupNorm table takes what the layer needs: with 8-row tiles and <= 256 normalised channels two
   // workgroups fit the 160 KiB of a CU
@@ -354,6 +366,11 @@ static int launch_patch(const ConvParams& p, hipStream_t st) {
 template <typename T, typename TO>
 static int launch_patch_th(const ConvParams& p, int th, hipStream_t st) {
   const bool gnp = p.gn_sums != nullptr;
+  if constexpr (sizeof(TO) == 4) {
+    // the 4-channel heads (f32 output): 16-channel tiles, 8 rows (2 waves, 50 KiB of LDS: three workgroups share a CU
+    // and the GroupNorm + SiLU of one's patch runs beside the others' MFMAs)
+    if (p.Cout <= 16) return gnp ? launch_patch<T, TO, 8, 16, true>(p, st) : launch_patch<T, TO, 8, 16, false>(p, st);
+  }
   if (th == 16) return gnp ? launch_patch<T, TO, 16, 128, true>(p, st) : launch_patch<T, TO, 16, 128, false>(p, st);
   return gnp ? launch_patch<T, TO, 8, 128, true>(p, st) : launch_patch<T, TO, 8, 128, false>(p, st);
 }

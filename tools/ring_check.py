@@ -112,7 +112,7 @@ def check():
         r = res[ringpol]
         d = (res[3][2] - r[2]).abs().max().item()
         print(f"{kw}: patch err {res[3][0]:.3e} stat {res[3][1]:.1e} | ring{'8' if ringpol & 16 else ''} (kind {r[3]}) err {r[0]:.3e} stat {r[1]:.1e} | ring vs patch {d:.3e}", flush=True)
-        assert r[3] == (4 if ringpol & 16 else 3), "the ring kernel did not take this case"
+        assert r[3] == 4 if ringpol & 16 else r[3] in (3, 4), "the ring kernel did not take this case"
         assert r[0] < 3e-2 and r[1] < 1e-5 and not math.isnan(r[0]), "ring kernel mismatch"
     hip.conv_policy(11)
 

@@ -215,23 +215,44 @@ class Bridge:
 
     # ---- black-box ODE solver (host loop, as in the reference) -----------
     def ode_sampler_int(self, model, y, rtol=1e-5, atol=1e-5, method="RK45", **kwargs):
-        """SciPy solve_ivp over the flattened complex state (bridge.py:115-140)."""
-        from scipy import integrate
+        """Adaptive integration of the probability-flow ODE over the complex state (bridge.py:115-140).
+
+        The reference flattens the state to numpy and calls SciPy's solve_ivp, moving it device -> host -> device for
+        every evaluation of the backbone.  With the state on a HIP device and method 'RK45' (the reference's default)
+        the same Dormand-Prince scheme with SciPy's step control runs with the state, the stages and the error norm
+        resident on the device (fdbm_amd/odeint.py); `device_state=False`, another `method`, or any other solve_ivp
+        option takes the SciPy route exactly as the reference does.  `self.last_ode_stats` = evaluations / steps."""
         noise = self._noise(y, kwargs)
         kwargs.pop("use_graph", None)
+        device_state = kwargs.pop("device_state", None)
+        if device_state is None:
+            device_state = y.is_cuda and method == "RK45" and set(kwargs) <= {"max_step", "first_step"}
         with torch.no_grad():
             x0 = self.prior_sampling(y, noise)
 
-            def rhs(t, x_flat):
-                x = torch.from_numpy(x_flat.reshape(tuple(y.shape))).to(y.device).type(torch.complex64)
+            def flow_of(t, x):
                 t_vec = torch.ones(y.shape[0], device=y.device) * t
                 s = model(x, y, t_vec)
-                flow = self._flow(t_vec, x, s, y)
-                return flow.detach().cpu().numpy().reshape((-1,))
+                return self._flow(t_vec, x, s, y)
+
+            if device_state:
+                from .odeint import rk45
+                assert method == "RK45", "device_state integrates with RK45 only"
+                x, stats = rk45(lambda t, x: flow_of(t, x.to(torch.complex64)), self.start_time, self.end_time, x0,
+                                rtol=rtol, atol=atol, **kwargs)
+                self.last_ode_stats = stats
+                return x.to(torch.complex64)
+
+            from scipy import integrate
+
+            def rhs(t, x_flat):
+                x = torch.from_numpy(x_flat.reshape(tuple(y.shape))).to(y.device).type(torch.complex64)
+                return flow_of(t, x).detach().cpu().numpy().reshape((-1,))
 
             sol = integrate.solve_ivp(rhs, (self.start_time, self.end_time),
                                       x0.detach().cpu().numpy().reshape((-1,)),
                                       rtol=rtol, atol=atol, method=method, **kwargs)
+            self.last_ode_stats = dict(nfev=int(sol.nfev), steps=int(sol.t.size - 1), rejected=None)
             x = torch.tensor(sol.y[:, -1]).reshape(y.shape).to(y.device).type(torch.complex64)
         return x
 

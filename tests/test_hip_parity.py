@@ -301,3 +301,28 @@ def test_program_export_and_c_loader(tmp_path):
     import numpy as np
     s = torch.from_numpy(np.frombuffer((tmp_path / "s.bin").read_bytes(), dtype=np.float32).copy()).reshape(ref.shape + (2,))
     assert torch.equal(s, torch.view_as_real(ref).cpu()), res.stdout
+
+
+def test_ode_int_device_matches_scipy(golden):
+    """`ode_sampler_int` with the state resident on the device (fdbm_amd/odeint.py, SciPy's RK45 restated) against
+    the reference's route through scipy.integrate.solve_ivp with host round trips (bridge.py:115-140), same backbone,
+    same noise: same number of backbone evaluations and steps, same result.  fm/ot and sb/bb, B = 2, the 5M backbone
+    with the contractive filler (the default filler's gain turns rounding differences of the two routes' fp64
+    reductions into different step decisions)."""
+    g = golden("samplers")
+    y = T(g["y"]).to(DEV)
+    y = torch.cat([y, 0.7 * torch.roll(y, 3, dims=-1)], 0)
+    hp = VARIANTS["ncsnpp_v2_5M"]
+    sd = fill_state_dict(Spec(**hp).param_shapes(), seed=0, profile="contractive")
+    m = HipNCSNpp(dtype=torch.float32, device=DEV, state={k: T(v) for k, v in sd.items()}, **hp)
+    for path in ("fm", "sb"):
+        br = fdbm_amd.Bridge(path, N=5, sampler_type="ode_int")
+        outs, stats = [], []
+        for dev_state in (True, False):
+            outs.append(br.sampler(m, y, generator=torch.Generator().manual_seed(11), rtol=1e-3, atol=1e-3,
+                                   device_state=dev_state))
+            stats.append(dict(br.last_ode_stats))
+        assert stats[0]["nfev"] == stats[1]["nfev"] and stats[0]["steps"] == stats[1]["steps"], (path, stats)
+        d = (outs[0] - outs[1]).abs().max().item()
+        assert d <= 2e-6 * max(1.0, outs[1].abs().max().item()), (path, d, stats)
+        assert torch.isfinite(torch.view_as_real(outs[0])).all()

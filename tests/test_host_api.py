@@ -3,6 +3,7 @@ tests/golden/coeffs.npz), sampler drivers with a plain callable model (vs the or
 behaviour, architecture bookkeeping, and that the C-ABI library loads and exports every symbol the
 header declares (no compute calls here: no GPU)."""
 import ctypes
+import math
 import os
 import re
 
@@ -234,3 +235,33 @@ def test_infer_driver_config_files(tmp_path):
     assert single.noisy_file == "a.wav" and single.output_file is None and single.N == 30
     with pytest.raises(SystemExit):
         infer.parse_args(["--ckpt", "m.ckpt"])
+
+
+def test_rk45_restatement_matches_scipy():
+    """fdbm_amd/odeint.py restates SciPy's RK45 (tableau, initial step, error norm, step control) so that the state can
+    stay on the device; on CPU tensors it must take the same steps as scipy.integrate.solve_ivp on the same problem."""
+    import numpy as np
+    import torch
+    from scipy import integrate
+    from fdbm_amd.odeint import rk45
+    rng = np.random.default_rng(3)
+    n = 257
+    lam = (-0.5 + 2.0j) * (1.0 + rng.random(n))
+    drive = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    y0 = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+    def f_np(t, y):
+        return lam * y + drive * np.cos(3.0 * t) + 0.1 * np.roll(y, 1) ** 2
+
+    lam_t, drive_t = torch.from_numpy(lam), torch.from_numpy(drive)
+
+    def f_t(t, y):
+        return lam_t * y + drive_t * math.cos(3.0 * t) + 0.1 * torch.roll(y, 1) ** 2
+
+    for (t0, t1, rtol, atol) in ((1.0, 0.03, 1e-5, 1e-5), (0.0, 2.0, 1e-3, 1e-6), (1.0, 1e-4, 1e-7, 1e-9)):
+        sol = integrate.solve_ivp(f_np, (t0, t1), y0, rtol=rtol, atol=atol, method="RK45")
+        y, st = rk45(f_t, t0, t1, torch.from_numpy(y0), rtol=rtol, atol=atol)
+        assert sol.status == 0
+        assert st["nfev"] == sol.nfev and st["steps"] == sol.t.size - 1, (st, sol.nfev, sol.t.size)
+        err = np.abs(y.numpy() - sol.y[:, -1]).max()
+        assert err < 1e-9 * max(1.0, np.abs(sol.y[:, -1]).max()), err

@@ -13,12 +13,15 @@ for B in ${@:-1 64}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_b$B -- python3 bench.py --batch $B --steps $steps --warmup 1 --no-cpu-baseline --no-extras > $O/bench_b${B}_under_rocprof.json 2> $O/stats_b$B.err
   cp "$(find $O/stats_b$B -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_b${B}_bf16.csv
   echo "stats B=$B done"
-  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_b$B -- python3 tools/pmc_workload.py $B $O/algo_b$B.json > $O/fetch_b$B.log 2>&1
+  # PMC passes over the SAME command (graph replays included; round 1's SIGSEGV under --pmc disappeared with the
+  # hipMemsetAsync graph node: tools/pmc_graph_repro.py), algorithmic bytes from a plain eager pass
+  python3 tools/pmc_workload.py $B $O/algo_b$B.json > $O/algo_b$B.log 2>&1
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_b$B -- python3 bench.py --batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/fetch_b$B.log 2>&1
   echo "fetch B=$B done"
-  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_b$B -- python3 tools/pmc_workload.py $B > $O/write_b$B.log 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_b$B -- python3 bench.py --batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/write_b$B.log 2>&1
   echo "write B=$B done"
   python3 tools/pmc_summarize.py $O/fetch_b$B $O/write_b$B $O/algo_b$B.json > $O/pmc_traffic_b${B}_bf16.json
-  if rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/sq_b$B -- python3 tools/pmc_workload.py $B > $O/sq_b$B.log 2>&1; then
+  if rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/sq_b$B -- python3 bench.py --batch $B --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/sq_b$B.log 2>&1; then
     python3 tools/pmc_sq_summarize.py $O/sq_b$B > $O/sq_counters_b${B}_bf16.txt 2>&1 || true
   else
     echo "sq pass failed (see $O/sq_b$B.log)"

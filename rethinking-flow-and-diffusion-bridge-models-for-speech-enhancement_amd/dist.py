@@ -61,3 +61,18 @@ def interleave(per_rank, n_items):
         for i in range(chunk.shape[0]):
             out[r + i * w] = chunk[i]
     return out
+
+
+def shard_by_length(lengths, world_size):
+    """Length-balanced sharding for batched folder inference (BASELINE configs[3]): utterances sorted by length,
+    longest first, each one given to the rank with the least total so far (LPT).  -> list of index lists, each in
+    descending length order (so that a rank's batches are formed from neighbours of similar length and every rank's
+    work ends within one utterance of the others').  Deterministic: ties go to the lower rank / lower index."""
+    order = sorted(range(len(lengths)), key=lambda i: (-int(lengths[i]), i))
+    shards = [[] for _ in range(max(1, world_size))]
+    load = [0] * max(1, world_size)
+    for i in order:
+        r = min(range(len(load)), key=lambda k: (load[k], k))
+        shards[r].append(i)
+        load[r] += int(lengths[i])
+    return shards

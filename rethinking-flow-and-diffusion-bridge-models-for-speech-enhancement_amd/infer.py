@@ -2,6 +2,7 @@
 
   python -m fdbm_amd.infer --ckpt model.ckpt --test_dir noisy/ --enhanced_dir out/ [--N 30]
          [--sampler_type ode_ei] [--sampler_kwargs "{...}"] [--keep_structure] [-D 0 1 2 ...] [-C config.yaml]
+         [--batch 64]
   python -m fdbm_amd.infer --ckpt model.ckpt --noisy_file a.wav [--output_file a_enhanced.wav] ...
 
 `-C file.yaml` reads the reference's config_infer_*.yaml files: `${key}` interpolation, `true` -> flag, null
@@ -12,6 +13,11 @@ Same arguments and per-file procedure as infer_folder.py:69-148: load, resample 
 ("noisy": peak, "std": standard deviation), STFT + compression + time padding, `bridge.sampler`,
 inverse transform, renormalise, clip to 0.95 if the peak exceeds 1, write.  One worker process per
 listed GPU over contiguous chunks of the sorted file list (infer_folder.py:150-230), no communication.
+
+`--batch B` (B > 1) is the batched form of the same thing (BASELINE configs[3]: 2 000 clips, batch 64, 8 GPUs): the
+GPUs get length-balanced shards of the file list (fdbm_amd.dist.shard_by_length), each worker buckets its files by
+padded spectrogram length and runs the sampler on up to B rows at a time (Enhancer.enhance_many); every file still gets
+its own normalisation factor, STFT, padding, inverse transform and clip rule, so its result is the one-at-a-time result.
 
 Differences, all on the audio-file side (the image has neither soundfile / torchaudio nor librosa):
 WAV is read and written with scipy.io.wavfile (PCM 8/16/24/32-bit and float; output float32 like
@@ -126,6 +132,65 @@ class Enhancer:
         return x_hat.cpu().numpy()
 
 
+    @torch.no_grad()
+    def enhance_many(self, waves, batch=8, clip=0.95, prior_noise_fn=None):
+        """Batched form of __call__ for a list of waveforms ([L] or [C, L] float32 at 16 kHz) -> list of [C, L] arrays.
+
+        Each file keeps the reference's per-file procedure (its own normalisation factor, STFT, time padding, inverse
+        transform with its own length, clip rule): only the sampler runs batched.  Rows (one per channel of a file)
+        are BUCKETED by padded frame count - a batch has one spectrogram shape - and buckets are processed longest
+        first in batches of up to `batch` rows, so a mixed-length folder costs one program / HIP graph per distinct
+        (rows, frames) instead of one per file.  A row's result does not depend on its batch mates (GroupNorm is per
+        sample: tests/test_hip_parity.py::test_batch64_rows_match_batch1).  prior_noise_fn(file_index, channel, row_shape)
+        -> complex tensor [1, F, Tpad]: the prior draw of one row (tests); default: the device generator, like the reference."""
+        self.fe.normalize = self.normalize
+        rows = []                                   # (frames, file index, channel, Y [1,F,Tpad], T_orig, nf scalar tensor)
+        chans = []
+        for fi, y in enumerate(waves):
+            y = torch.as_tensor(y, dtype=torch.float32)
+            if y.dim() == 1:
+                y = y[None]
+            chans.append(y.shape[0])
+            y = y.to(self.device)
+            nf = self.fe.norm_factor(y)
+            if y.shape[0] > 1:
+                nf = (nf.max() if self.normalize != "std" else y.std()).expand(y.shape[0]).contiguous()
+            Y = self.fe.spec_forward_padded(y, self.pad_mode, norm=nf)            # [C,1,F,Tpad]
+            for c in range(y.shape[0]):
+                rows.append((int(Y.shape[-1]), fi, c, Y[c], int(y.shape[-1]), nf[c:c + 1]))
+        order = sorted(range(len(rows)), key=lambda i: (-rows[i][0], rows[i][1], rows[i][2]))
+        out = [[None] * c for c in chans]
+        self.batch_shapes = []                      # (rows, frames) of every sampler call (for tests / logs)
+        i = 0
+        while i < len(order):
+            frames = rows[order[i]][0]
+            j = i
+            while j < len(order) and j - i < batch and rows[order[j]][0] == frames:
+                j += 1
+            idx = order[i:j]
+            Y = torch.stack([rows[k][3] for k in idx], 0)                          # [b,1,F,Tpad]
+            kw = dict(self.sampler_kwargs)
+            if prior_noise_fn is not None:
+                kw["prior_noise"] = torch.stack([prior_noise_fn(rows[k][1], rows[k][2], tuple(rows[k][3].shape)) for k in idx], 0)
+            sample = self.bridge.sampler(self.net, Y, **kw)
+            self.batch_shapes.append((len(idx), frames))
+            for r, k in enumerate(idx):
+                _, fi, c, _, T_orig, nf = rows[k]
+                mono = chans[fi] == 1
+                x = self.fe.to_audio(sample[r:r + 1, 0], T_orig, norm=nf, clip=clip if mono else 0.0)
+                out[fi][c] = x[0]
+            i = j
+        res = []
+        for fi, per_c in enumerate(out):
+            x_hat = torch.stack(per_c, 0)
+            if len(per_c) > 1:
+                peak = x_hat.abs().max()                                           # over all channels (infer_folder.py:119-121)
+                if peak > 1.0:
+                    x_hat = x_hat / peak * clip
+            res.append(x_hat.cpu().numpy())
+        return res
+
+
 def output_path(noisy_file, args):
     if args.keep_structure:
         return join(args.enhanced_dir, os.path.relpath(noisy_file, args.test_dir))
@@ -155,8 +220,53 @@ def enhance_files(gpu_id, file_list, args, counter=None):
     return done
 
 
+def wav_num_samples(path):
+    """Length of a WAV file in samples at 16 kHz, from its header / size alone (for length-balanced sharding)."""
+    try:
+        import wave
+        with wave.open(path, "rb") as w:
+            return int(w.getnframes() * TARGET_SR / max(1, w.getframerate()))
+    except Exception:                      # float WAVs and the like: the file size orders them well enough
+        return os.path.getsize(path) // 2
+
+
+def enhance_files_batched(gpu_id, file_list, args, counter=None):
+    """Worker of the batched mode (--batch B > 1): its shard of the file list in windows of 4 B files, each window
+    bucketed by padded length and enhanced B rows at a time (Enhancer.enhance_many).  Returns #files written."""
+    enh = Enhancer(args.ckpt, device=f"cuda:{gpu_id}", N=args.N, sampler_type=args.sampler_type,
+                   sampler_kwargs=args.sampler_kwargs, dtype=torch.float32 if args.fp32 else torch.bfloat16)
+    done = 0
+    win = max(1, 4 * args.batch)
+    for w0 in range(0, len(file_list), win):
+        names, waves = [], []
+        for noisy_file in file_list[w0:w0 + win]:
+            try:
+                if noisy_file.lower().endswith(".flac"):
+                    raise RuntimeError("FLAC input needs an audio library this build does not have; convert to WAV")
+                y, sr = read_wav(noisy_file)
+                waves.append(resample_to(y, sr))
+                names.append(noisy_file)
+            except Exception as e:
+                print(f"\nError processing {noisy_file} on GPU {gpu_id}: {e}")
+        try:
+            outs = enh.enhance_many(waves, batch=args.batch) if waves else []
+        except Exception as e:          # like the reference: report, count, go on (here: the whole window)
+            print(f"\nError processing a window of {len(waves)} files on GPU {gpu_id}: {e}")
+            outs = []
+            names = []
+        for noisy_file, x_hat in zip(names, outs):
+            out = output_path(noisy_file, args)
+            os.makedirs(dirname(out) or ".", exist_ok=True)
+            write_wav(out, x_hat[0] if x_hat.shape[0] == 1 else x_hat)
+            done += 1
+        if counter is not None:
+            with counter.get_lock():
+                counter.value += len(file_list[w0:w0 + win])
+    return done
+
+
 def enhance_folder(args):
-    from .dist import split_list
+    from .dist import split_list, shard_by_length
     files = get_audio_files(args.test_dir)
     if not files:
         print(f"No audio files found in {args.test_dir}")
@@ -165,16 +275,25 @@ def enhance_folder(args):
     os.makedirs(args.enhanced_dir, exist_ok=True)
     gpus = [int(d) for d in args.device]
     print(f"Using {len(gpus)} GPU(s): {','.join(map(str, gpus))}")
+    batched = getattr(args, "batch", 1) > 1
+    worker = enhance_files_batched if batched else enhance_files
+    if batched:
+        # length-balanced shards (every GPU gets the same amount of audio, its files in descending length order so
+        # that batch mates have the same padded length); the reference's contiguous chunks otherwise
+        shards = shard_by_length([wav_num_samples(f) for f in files], len(gpus))
+        chunks = [[files[i] for i in sh] for sh in shards]
+    else:
+        chunks = split_list(files, len(gpus))
     if len(gpus) == 1:
-        n = enhance_files(gpus[0], files, args)
+        n = worker(gpus[0], chunks[0], args)
     else:
         import torch.multiprocessing as mp
         ctx = mp.get_context("spawn")
         counter = ctx.Value("i", 0)
         procs = []
-        for gpu, chunk in zip(gpus, split_list(files, len(gpus))):
+        for gpu, chunk in zip(gpus, chunks):
             if chunk:
-                p = ctx.Process(target=enhance_files, args=(gpu, chunk, args, counter))
+                p = ctx.Process(target=worker, args=(gpu, chunk, args, counter))
                 p.start()
                 procs.append(p)
         for p in procs:
@@ -245,6 +364,9 @@ def build_parser():
     p.add_argument("--N", type=int, default=30)
     p.add_argument("--keep_structure", action="store_true")
     p.add_argument("--fp32", action="store_true", help="f32 parity mode instead of bf16 storage")
+    p.add_argument("--batch", type=int, default=1,
+                   help="rows per sampler call: > 1 buckets the files by padded length, balances the GPUs by audio length "
+                        "and runs the sampler batched (BASELINE configs[3]); 1 = one file at a time, like the reference")
     return p
 
 

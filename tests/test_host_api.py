@@ -265,3 +265,21 @@ def test_rk45_restatement_matches_scipy():
         assert st["nfev"] == sol.nfev and st["steps"] == sol.t.size - 1, (st, sol.nfev, sol.t.size)
         err = np.abs(y.numpy() - sol.y[:, -1]).max()
         assert err < 1e-9 * max(1.0, np.abs(sol.y[:, -1]).max()), err
+
+
+def test_shard_by_length_balances_and_covers():
+    """Length-balanced sharding of the batched folder driver (fdbm_amd.dist.shard_by_length): every index once, shards in
+    descending length order, totals within one longest utterance of each other, deterministic."""
+    from fdbm_amd.dist import shard_by_length
+    rng = np.random.default_rng(0)
+    lengths = rng.integers(8000, 160000, size=203).tolist()
+    for w in (1, 2, 3, 8):
+        sh = shard_by_length(lengths, w)
+        assert sorted(i for s_ in sh for i in s_) == list(range(len(lengths)))
+        tot = [sum(lengths[i] for i in s_) for s_ in sh]
+        assert max(tot) - min(tot) <= max(lengths)
+        for s_ in sh:
+            ls = [lengths[i] for i in s_]
+            assert ls == sorted(ls, reverse=True)
+        assert sh == shard_by_length(lengths, w)
+    assert shard_by_length([], 4) == [[], [], [], []]

@@ -419,6 +419,43 @@ def gen_config0():
     save("config0_sample1", pcm=pcm, Y=Y, sample=sample, x_hat=x_hat, norm=np.array(float(nf)))
 
 
+# ---- TF-GridNet backbone (fdbm/backbones/tfgridnet.py) ---------------------------------------------
+def gen_tfgridnet():
+    """Reference TFGridNet_4l32c80 / _5l32c100 with the oracle's deterministic filler: one evaluation on small inputs
+    (the model is independent of F and T), plus the output of the stem and of the first block for localisation."""
+    from fdbm.backbones import tfgridnet as rt
+    from oracle import tfgridnet as ot
+    for name, cls, (B, Fq, T) in (("tfgridnet_4l32c80", rt.TFGridNet_4l32c80, (2, 257, 24)),
+                                  ("tfgridnet_5l32c100", rt.TFGridNet_5l32c100, (1, 65, 40))):
+        m = cls().eval()
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        assert shapes == ot.param_shapes(**ot.VARIANTS[name]), name
+        assert list(shapes) == list(ot.param_shapes(**ot.VARIANTS[name])), "registration order"
+        sd = ot.fill_state(shapes, seed=0)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        g = np.random.Generator(np.random.Philox(77 + B))
+        def cplx(scale):
+            return torch.from_numpy((scale * (g.standard_normal((B, 1, Fq, T)) + 1j * g.standard_normal((B, 1, Fq, T)))).astype(np.complex64))
+        x, y = cplx(0.5), cplx(0.4)
+        t = torch.tensor([0.63, 0.21][:B], dtype=torch.float32)
+        out = m(x, y, t)
+        # intermediate: stem (conv + GroupNorm) and the first block's output, as the reference computes them
+        inp = torch.cat((x.real, x.imag, y.real, y.imag), dim=1).permute(0, 1, 3, 2)
+        stem = m.conv(inp)
+        temb = m.time_emb_fc(m.get_time_emb(torch.log(t)))
+        b0 = m.blocks[0](m.time_emb_blocks[0](temb)[:, :, None, None] + stem)
+        extra = {}
+        if Fq * T <= 4096:              # the small case also keeps every block's output (teacher-forced per-block checks)
+            h = stem
+            for i in range(m.n_layers):
+                h = m.blocks[i](m.time_emb_blocks[i](temb)[:, :, None, None] + h)
+                extra[f"block{i}"] = h
+        mine = ot.Model(sd, ot.VARIANTS[name])(x, y, t)
+        print(f"{name}: |out| max {out.abs().max():.3f}, oracle vs reference {float((mine - out).abs().max()):.2e}")
+        extra.setdefault("block0", b0)
+        save(name, x=x, y=y, t=t, out=out, stem=stem, **extra)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None)

@@ -168,3 +168,32 @@ def test_sampler_batched(golden):
     smp = osamp.Sampler("sb", N=3, noise_schedule="bb")
     out = smp.ode_ei(model, T(g["mini64_y"]), torch.Generator().manual_seed(99))
     assert maxabs(out, g["mini64_sb_bb_ode_ei_N3"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["tfgridnet_4l32c80", "tfgridnet_5l32c100"])
+def test_tfgridnet_oracle_vs_reference(golden, name):
+    """oracle/tfgridnet.py against outputs of the reference's TFGridNet (tests/golden/make_golden.py gen_tfgridnet):
+    the stem bit for bit, one block to fp32 rounding (both sit ~2e-5 from an fp64 evaluation of the same block), the
+    whole net within what 4-5 recurrent blocks make of that (1.3e-3 at |out| <= 10)."""
+    import torch.nn.functional as F
+    from oracle import tfgridnet as ot
+    g = golden(name)
+    hp = ot.VARIANTS[name]
+    sd = {k: T(v) for k, v in ot.fill_state(ot.param_shapes(**hp)).items()}
+    x, y, t = T(g["x"]), T(g["y"]), T(g["t"])
+    m = ot.Model(sd, hp)
+    out = m(x, y, t)
+    assert maxabs(out, g["out"]) < 3e-3
+    stem = T(g["stem"])
+    proj = torch.log(t)[:, None] * sd["get_time_emb.W"][None, :] * 2 * np.pi
+    temb = torch.cat([torch.sin(proj), torch.cos(proj)], dim=-1)
+    temb = F.silu(F.linear(temb, sd["time_emb_fc.0.weight"], sd["time_emb_fc.0.bias"]))
+    temb = F.silu(F.linear(temb, sd["time_emb_fc.2.weight"], sd["time_emb_fc.2.bias"]))
+    h = stem
+    for i in range(hp["n_layers"]):
+        if f"block{i}" not in g:
+            break
+        tb = F.linear(temb, sd[f"time_emb_blocks.{i}.weight"], sd[f"time_emb_blocks.{i}.bias"])[:, :, None, None]
+        o = ot.block(tb + h, sd, f"blocks.{i}.", hp.get("attn_n_head", 4), 4, 1e-5)
+        assert maxabs(o, g[f"block{i}"]) < 1.5e-4, i           # teacher-forced: the reference's own input to this block
+        h = T(g[f"block{i}"])

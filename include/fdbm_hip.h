@@ -391,6 +391,31 @@ int64_t fdbm_program_weights_bytes(const void* program, int64_t nbytes);
 fdbm_ncsnpp_ctx* fdbm_ncsnpp_create_from_program(const void* program, int64_t nbytes, void* weights_dev,
                                                  void* workspace_dev, int64_t workspace_bytes);
 
+/* ---- TF-GridNet backbone (fdbm/backbones/tfgridnet.py:83-510; BackboneRegistry "tfgridnet_5l32c100", "tfgridnet_4l32c80") ----
+ * The context the survey asks for at this boundary: created from an architecture descriptor + ONE flat f32 weight blob
+ * on the device, evaluated on caller-owned buffers (f32 throughout).  Blob order (fdbm_amd/tfgridnet.py:pack_state):
+ *   stem conv w [C][3][3][in_ch], b [C]; GroupNorm gamma, beta [C];
+ *   per block, for r in (intra, inter): LayerNorm gamma, beta [C]; W_in [8H][ks*C] (rows: forward i f g o | reverse i f g o;
+ *     column i*C + c = weight_ih[.., c*ks + i]), b_in [8H] = bias_ih + bias_hh; W_hh forward [4H][H], reverse [4H][H];
+ *     W_dec [C][ks*2H] (column j*2H + h = ConvTranspose1d weight[h][c][ks-1-j]), b_dec [C];
+ *   then W_qkv [2 nh E + C][C] (attn_conv_Q | K | V), b_qkv; PReLU slopes [3][nh]; head-norm gamma, beta [2 nh E + C];
+ *     W_proj [C][C], b_proj [C]; PReLU slope [1]; LayerNormalization gamma, beta [C];
+ *   head conv (ConvTranspose2d as a convolution) w [out_ch][3][3][C] (= deconv.weight[c][o][2-ky][2-kx]), b [out_ch];
+ *   Fourier W [C]; time_emb_fc.0 w [4C][2C], b; time_emb_fc.2 w [4C][4C], b; time_emb_blocks w [n_layers][C][4C], b [n_layers][C]. */
+typedef struct fdbm_tfgridnet_desc {
+  int32_t n_layers, emb_dim, hidden, emb_ks, n_head, qk_channels, in_ch, out_ch;   /* in_ch = 4, out_ch = 2 */
+  float eps;
+} fdbm_tfgridnet_desc;
+typedef struct fdbm_tfgridnet_ctx fdbm_tfgridnet_ctx;
+int64_t fdbm_tfgridnet_weights_count(const fdbm_tfgridnet_desc* d);                 /* floats in the blob; < 0: unsupported */
+int64_t fdbm_tfgridnet_workspace_bytes(const fdbm_tfgridnet_desc* d, int B, int F, int T);
+fdbm_tfgridnet_ctx* fdbm_tfgridnet_create(const fdbm_tfgridnet_desc* d, const float* weights_dev, int64_t n_weights);
+void fdbm_tfgridnet_destroy(fdbm_tfgridnet_ctx* ctx);
+/* model(x, y, t) of tfgridnet.py:194-232: x, y, out complex64 [B][1][F][T]; log_t f32 [B] = log(t) evaluated on the host;
+ * block_out (may be NULL): f32 [n_layers][B][T][F][C], every block's output (parity tests). */
+int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* ctx, const void* x, const void* y, const float* log_t, void* out,
+                           int B, int F, int T, void* workspace, int64_t workspace_bytes, float* block_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,7 +89,9 @@ _SIGS = {
 EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc", "fdbm_conv_plan",
                                 "fdbm_conv_plan_ex", "fdbm_conv_policy", "fdbm_conv_last_kind", "fdbm_runtime_init_side", "fdbm_ncsnpp_create", "fdbm_ncsnpp_destroy",
                                 "fdbm_ncsnpp_forward", "fdbm_program_workspace_bytes", "fdbm_program_weights_bytes",
-                                "fdbm_ncsnpp_create_from_program"])
+                                "fdbm_ncsnpp_create_from_program", "fdbm_tfgridnet_weights_count",
+                                "fdbm_tfgridnet_workspace_bytes", "fdbm_tfgridnet_create", "fdbm_tfgridnet_destroy",
+                                "fdbm_tfgridnet_forward"])
 
 
 def lib():
@@ -132,6 +134,17 @@ def lib():
         L.fdbm_program_weights_bytes.restype = c_i64
         L.fdbm_ncsnpp_create_from_program.argtypes = [c_void_p, c_i64, c_void_p, c_void_p, c_i64]
         L.fdbm_ncsnpp_create_from_program.restype = c_void_p
+        L.fdbm_tfgridnet_weights_count.argtypes = [c_void_p]
+        L.fdbm_tfgridnet_weights_count.restype = c_i64
+        L.fdbm_tfgridnet_workspace_bytes.argtypes = [c_void_p, c_int, c_int, c_int]
+        L.fdbm_tfgridnet_workspace_bytes.restype = c_i64
+        L.fdbm_tfgridnet_create.argtypes = [c_void_p, c_void_p, c_i64]
+        L.fdbm_tfgridnet_create.restype = c_void_p
+        L.fdbm_tfgridnet_destroy.argtypes = [c_void_p]
+        L.fdbm_tfgridnet_destroy.restype = None
+        L.fdbm_tfgridnet_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                             c_void_p, c_i64, c_void_p, c_void_p]
+        L.fdbm_tfgridnet_forward.restype = c_int
         _lib = L
     return _lib
 

@@ -326,3 +326,29 @@ def test_ode_int_device_matches_scipy(golden):
         d = (outs[0] - outs[1]).abs().max().item()
         assert d <= 2e-6 * max(1.0, outs[1].abs().max().item()), (path, d, stats)
         assert torch.isfinite(torch.view_as_real(outs[0])).all()
+
+
+@pytest.mark.parametrize("name", ["tfgridnet_5l32c100", "tfgridnet_4l32c80"])
+def test_tfgridnet_vs_reference(golden, name):
+    """TF-GridNet through the C ABI (fdbm_tfgridnet_create from a weight blob + descriptor, fdbm_tfgridnet_forward) against
+    outputs of the reference's TFGridNet: every block's output (free-running from the stem; the fixture keeps all blocks
+    for the small case) and the final complex spectrogram.  One block is accurate to fp32 rounding (the oracle sits
+    2.6e-5 from the reference after block 0, both ~2e-5 from fp64); 4-5 recurrent blocks amplify that to 1e-3 at
+    |out| <= 10 - the bound is the oracle-vs-reference spread of tests/test_oracle_golden.py."""
+    g = golden(name)
+    m = fdbm_amd.BackboneRegistry.get_by_name(name)(device=DEV)
+    x, y, t = T(g["x"]).to(DEV), T(g["y"]).to(DEV), T(g["t"]).to(DEV)
+    out, blocks = m(x, y, t, block_out=True)
+    b0 = blocks[0].permute(0, 3, 1, 2).cpu()                       # [B,T,F,C] -> [B,C,T,F]
+    e0 = (b0 - T(g["block0"])).abs().max().item()
+    assert e0 < 1.5e-4, e0
+    if "block1" in g:
+        for i in range(1, blocks.shape[0]):
+            ei = (blocks[i].permute(0, 3, 1, 2).cpu() - T(g[f"block{i}"])).abs().max().item()
+            assert ei < 2e-3, (i, ei)
+    err = (out.cpu() - T(g["out"])).abs().max().item()
+    assert err < 3e-3, err
+    # the registry object is the model(x, y, t) callable the samplers take
+    br = fdbm_amd.Bridge("fm", N=2, sampler_type="ode_ei")
+    s = br.sampler(m, y, generator=torch.Generator().manual_seed(3))
+    assert s.shape == y.shape and torch.isfinite(torch.view_as_real(s)).all()

@@ -37,7 +37,8 @@ def test_registry_behaviour():
     with pytest.raises(ValueError):
         r.get_by_name("missing")
     assert set(fdbm_amd.BridgeRegistry.get_all_names()) == {"sb", "fm"}
-    assert set(fdbm_amd.BackboneRegistry.get_all_names()) == set(VARIANTS)
+    from fdbm_amd.tfgridnet import VARIANTS as TFG_VARIANTS
+    assert set(fdbm_amd.BackboneRegistry.get_all_names()) == set(VARIANTS) | set(TFG_VARIANTS)
     assert {"euler_maruyama", "none"} <= set(fdbm_amd.PredictorRegistry.get_all_names())
     assert {"langevin", "ald", "none"} <= set(fdbm_amd.CorrectorRegistry.get_all_names())
 

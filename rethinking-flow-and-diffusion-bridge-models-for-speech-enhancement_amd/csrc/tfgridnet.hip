@@ -150,7 +150,7 @@ __global__ void tfg_transpose_crop(float* __restrict__ out, const float* __restr
 
 // ---- GEMM: out[m][n] = sum_k A(m)[k] * W[n][k] + bias[n] (+ res[m][n]) ---------------------------------------------
 // A(m) = A + (m / rps) * seq_stride + (m % rps) * lda : rows may be overlapping windows (unfold).  out likewise with
-// (out_seq_stride, ldo).  grid.z = batch with (sA, sW, sO) strides.  64 x 64 tile, 256 threads x (4 x 4), K-step 16.
+// (out_seq_stride, ldo).  grid.z = batch with (sA, sW, sO) strides.  64 x 64 tile, 4 waves x (2 x 2 MFMA tiles), K-step 16.
 struct GemmArgs {
   float* out; const float* A; const float* W; const float* bias; const float* res;
   int64_t M; int N, K;
@@ -160,22 +160,30 @@ struct GemmArgs {
 };
 
 __global__ void __launch_bounds__(256) tfg_gemm(const GemmArgs g) {
+  // v_mfma_f32_16x16x4_f32: the W tile is the A operand (lane: row n = lane % 16, k = lane / 16), the activation tile the
+  // B operand (column m = lane % 16, k = lane / 16); a lane's 4 results are 4 consecutive n of one m.
   __shared__ float As[16][64 + 4], Ws[16][64 + 4];
   const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;             // wave's 32 x 32 quadrant of the 64 (m) x 64 (n) tile
   const int64_t m0 = (int64_t)blockIdx.x * 64;
   const int n0 = blockIdx.y * 64;
   const float* A = g.A + (int64_t)blockIdx.z * g.sA;
   const float* W = g.W + (int64_t)blockIdx.z * g.sW;
   float* out = g.out + (int64_t)blockIdx.z * g.sO;
-  const int tm = tid / 16, tn = tid % 16;          // thread's 4 x 4 sub-tile: rows tm*4.., cols tn*4..
-  float acc[4][4] = {};
+  f32x4 acc[2][2];                                      // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   // loader: thread loads 4 consecutive k of one row (row = tid / 4, k4 = (tid % 4) * 4) for A and for W
   const int lr = tid >> 2, lk = (tid & 3) * 4;
   const int64_t am = m0 + lr;
   const float* arow = nullptr;
   if (am < g.M) arow = A + (am / g.rps) * g.seq_stride + (am % g.rps) * (int64_t)g.lda;
-  const int wn = n0 + lr;
-  const float* wrow = wn < g.N ? W + (int64_t)wn * g.K : nullptr;
+  const int wr = n0 + lr;
+  const float* wrow = wr < g.N ? W + (int64_t)wr * g.K : nullptr;
+  const int fr = lane & 15, fk = lane >> 4;
   for (int k0 = 0; k0 < g.K; k0 += 16) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -185,30 +193,35 @@ __global__ void __launch_bounds__(256) tfg_gemm(const GemmArgs g) {
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      float a[4], b[4];
+    for (int kg = 0; kg < 4; ++kg) {
+      float wv[2], av[2];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { a[i] = As[k][tm * 4 + i]; b[i] = Ws[k][tn * 4 + i]; }
+      for (int i = 0; i < 2; ++i) {
+        wv[i] = Ws[kg * 4 + fk][wn * 32 + i * 16 + fr];
+        av[i] = As[kg * 4 + fk][wm * 32 + i * 16 + fr];
+      }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[i], av[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
   }
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int64_t m = m0 + tm * 4 + i;
+  for (int j = 0; j < 2; ++j) {
+    const int64_t m = m0 + wm * 32 + j * 16 + fr;
     if (m >= g.M) continue;
-    float* orow = out + (m / g.rps) * g.out_seq_stride + (m % g.rps) * (int64_t)g.ldo;
+    const int64_t ooff = (m / g.rps) * g.out_seq_stride + (m % g.rps) * (int64_t)g.ldo;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tn * 4 + j;
-      if (n >= g.N) continue;
-      float v = acc[i][j] * g.scale + (g.bias ? g.bias[n] : 0.f);
-      if (g.res) v += g.res[(m / g.rps) * g.out_seq_stride + (m % g.rps) * (int64_t)g.ldo + n];
-      orow[n] = v;
-    }
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + wn * 32 + i * 16 + fk * 4 + r;
+        if (n >= g.N) continue;
+        float v = acc[i][j][r] * g.scale + (g.bias ? g.bias[n] : 0.f);
+        if (g.res) v += g.res[ooff + n];
+        out[ooff + n] = v;
+      }
   }
 }
 
@@ -233,10 +246,14 @@ __global__ void __launch_bounds__(4 * HMAX) tfg_lstm(float* __restrict__ hout, c
   const float* gseq = G + (int64_t)seq * L * 8 * H + dir * 4 * H;
   float* hseq = hout + ((int64_t)seq * (L + 2 * hp) + hp) * 2 * H + dir * H;
   __syncthreads();
+  // (the next step's input pre-activation is requested a step ahead: its load latency would otherwise sit in every one
+  // of the L dependent steps)
+  float gnext = (r < 4 * H) ? gseq[(int64_t)(dir ? L - 1 : 0) * 8 * H + r] : 0.f;
   for (int s = 0; s < L; ++s) {
     const int t = dir ? L - 1 - s : s;
     if (r < 4 * H) {
-      float acc = gseq[(int64_t)t * 8 * H + r];
+      float acc = gnext;
+      if (s + 1 < L) gnext = gseq[(int64_t)(dir ? t - 1 : t + 1) * 8 * H + r];
 #pragma unroll
       for (int k = 0; k < HMAX; k += 4) {
         const float4 hv = *reinterpret_cast<const float4*>(&s_h[k]);
@@ -527,6 +544,7 @@ extern "C" int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* c, const void* x, cons
                           (int64_t)L * 8 * H, 8 * H)) return 1;
       FDBM_CHECK(fdbm_memset_zero(hbuf, (((nseq * (L + 2 * olp) * 2 * H + (int64_t)ks * 2 * H) * 4 + 15) / 16) * 16, st) == 0, "fdbm_tfgridnet_forward: memset failed");
       if (H <= 80) tfg_lstm<80><<<dim3((unsigned)nseq, 2), 320, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], L, H, olp);
+      else if (H <= 100) tfg_lstm<100><<<dim3((unsigned)nseq, 2), 400, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], L, H, olp);
       else tfg_lstm<128><<<dim3((unsigned)nseq, 2), 512, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], L, H, olp);
       FDBM_LAUNCH_CHECK("fdbm_tfgridnet_forward(lstm)");
       // ConvTranspose1d(2H -> C, ks) + bias + residual: rows = windows of ks*2H floats of the zero-bordered sequence buffer

@@ -5,7 +5,7 @@ nfwd = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
 tot = 0.0
 out = []
 for r in rows:
-    name = re.sub(r"\(.*", "", r["Name"])
+    name = re.sub(r"\(.*", "", r["Name"].replace("(anonymous namespace)::", ""))
     name = re.sub(r"^void ", "", name)
     t = float(r["TotalDurationNs"]) / 1e3 / nfwd
     out.append((t, name[:78], int(r["Calls"]) / nfwd, float(r["AverageNs"]) / 1e3))

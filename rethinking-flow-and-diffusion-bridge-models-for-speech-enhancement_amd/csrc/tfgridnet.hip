@@ -232,43 +232,62 @@ __global__ void __launch_bounds__(256) tfg_gemm(const GemmArgs g) {
 template <int HMAX>
 __global__ void __launch_bounds__(4 * HMAX) tfg_lstm(float* __restrict__ hout, const float* __restrict__ G,
                                                      const float* __restrict__ whh_f, const float* __restrict__ whh_b,
-                                                     int L, int H, int hp) {
-  __shared__ __attribute__((aligned(16))) float s_h[HMAX];
-  __shared__ float s_g[4 * HMAX];
-  const int seq = blockIdx.x, dir = blockIdx.y;
+                                                     int nseq, int L, int H, int hp) {
+  // TWO sequences per workgroup share the register-resident W_hh rows: 263 sequences x 2 directions are then 264
+  // workgroups - one round over the 256 CUs (one 7-wave workgroup with 134 VGPRs fits a CU) instead of three.
+  constexpr int NS = 2;
+  __shared__ __attribute__((aligned(16))) float s_h[NS][HMAX];
+  __shared__ float s_g[NS][4 * HMAX];
+  const int seq0 = blockIdx.x * NS, dir = blockIdx.y;
   const int r = threadIdx.x;
   const float* whh = dir ? whh_b : whh_f;
   float w[HMAX];
 #pragma unroll
   for (int k = 0; k < HMAX; ++k) w[k] = (r < 4 * H && k < H) ? whh[(int64_t)r * H + k] : 0.f;
-  if (r < HMAX) s_h[r] = 0.f;
-  float c = 0.f;
-  const float* gseq = G + (int64_t)seq * L * 8 * H + dir * 4 * H;
-  float* hseq = hout + ((int64_t)seq * (L + 2 * hp) + hp) * 2 * H + dir * H;
+  for (int i = r; i < NS * HMAX; i += blockDim.x) (&s_h[0][0])[i] = 0.f;
+  float c = 0.f;                                   // cell state of (sequence r / H, unit r % H) for r < NS * H
+  const float* gseq[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) gseq[q] = G + (int64_t)min(seq0 + q, nseq - 1) * L * 8 * H + dir * 4 * H;
+  const int uq = r / H, uu = r - uq * H;            // this thread's (sequence, unit) in the gate phase
+  float* hseq = hout + ((int64_t)min(seq0 + uq, nseq - 1) * (L + 2 * hp) + hp) * 2 * H + dir * H + uu;
+  const bool ulive = r < NS * H && seq0 + uq < nseq;
   __syncthreads();
   // (the next step's input pre-activation is requested a step ahead: its load latency would otherwise sit in every one
   // of the L dependent steps)
-  float gnext = (r < 4 * H) ? gseq[(int64_t)(dir ? L - 1 : 0) * 8 * H + r] : 0.f;
+  float gnext[NS];
+#pragma unroll
+  for (int q = 0; q < NS; ++q) gnext[q] = (r < 4 * H) ? gseq[q][(int64_t)(dir ? L - 1 : 0) * 8 * H + r] : 0.f;
   for (int s = 0; s < L; ++s) {
     const int t = dir ? L - 1 - s : s;
     if (r < 4 * H) {
-      float acc = gnext;
-      if (s + 1 < L) gnext = gseq[(int64_t)(dir ? t - 1 : t + 1) * 8 * H + r];
+      float acc[NS];
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        acc[q] = gnext[q];
+        if (s + 1 < L) gnext[q] = gseq[q][(int64_t)(dir ? t - 1 : t + 1) * 8 * H + r];
+      }
 #pragma unroll
       for (int k = 0; k < HMAX; k += 4) {
-        const float4 hv = *reinterpret_cast<const float4*>(&s_h[k]);
-        acc = fmaf(w[k], hv.x, acc); acc = fmaf(w[k + 1], hv.y, acc); acc = fmaf(w[k + 2], hv.z, acc); acc = fmaf(w[k + 3], hv.w, acc);
+#pragma unroll
+        for (int q = 0; q < NS; ++q) {
+          const float4 hv = *reinterpret_cast<const float4*>(&s_h[q][k]);
+          acc[q] = fmaf(w[k], hv.x, acc[q]); acc[q] = fmaf(w[k + 1], hv.y, acc[q]);
+          acc[q] = fmaf(w[k + 2], hv.z, acc[q]); acc[q] = fmaf(w[k + 3], hv.w, acc[q]);
+        }
       }
-      s_g[r] = acc;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) s_g[q][r] = acc[q];
     }
     __syncthreads();
-    if (r < H) {
-      const float ig = 1.f / (1.f + expf(-s_g[r])), fg = 1.f / (1.f + expf(-s_g[H + r]));
-      const float gg = tanhf(s_g[2 * H + r]), og = 1.f / (1.f + expf(-s_g[3 * H + r]));
+    if (r < NS * H) {
+      const float* gq = s_g[uq];
+      const float ig = 1.f / (1.f + expf(-gq[uu])), fg = 1.f / (1.f + expf(-gq[H + uu]));
+      const float gg = tanhf(gq[2 * H + uu]), og = 1.f / (1.f + expf(-gq[3 * H + uu]));
       c = fg * c + ig * gg;
       const float h = og * tanhf(c);
-      s_h[r] = h;
-      hseq[(int64_t)t * 2 * H + r] = h;
+      s_h[uq][uu] = h;
+      if (ulive) hseq[(int64_t)t * 2 * H] = h;
     }
     __syncthreads();
   }
@@ -543,9 +562,10 @@ extern "C" int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* c, const void* x, cons
       if (tfg_gemm_launch(st, G, n1, wt + b.win[r], wt + b.bin[r], nullptr, nseq * L, 8 * H, ks * C, L, (int64_t)Sl * C, C,
                           (int64_t)L * 8 * H, 8 * H)) return 1;
       FDBM_CHECK(fdbm_memset_zero(hbuf, (((nseq * (L + 2 * olp) * 2 * H + (int64_t)ks * 2 * H) * 4 + 15) / 16) * 16, st) == 0, "fdbm_tfgridnet_forward: memset failed");
-      if (H <= 80) tfg_lstm<80><<<dim3((unsigned)nseq, 2), 320, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], L, H, olp);
-      else if (H <= 100) tfg_lstm<100><<<dim3((unsigned)nseq, 2), 400, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], L, H, olp);
-      else tfg_lstm<128><<<dim3((unsigned)nseq, 2), 512, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], L, H, olp);
+      const dim3 lgrid((unsigned)((nseq + 1) / 2), 2);
+      if (H <= 80) tfg_lstm<80><<<lgrid, 320, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)nseq, L, H, olp);
+      else if (H <= 100) tfg_lstm<100><<<lgrid, 400, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)nseq, L, H, olp);
+      else tfg_lstm<128><<<lgrid, 512, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)nseq, L, H, olp);
       FDBM_LAUNCH_CHECK("fdbm_tfgridnet_forward(lstm)");
       // ConvTranspose1d(2H -> C, ks) + bias + residual: rows = windows of ks*2H floats of the zero-bordered sequence buffer
       float* dst = r == 0 ? x2 : x3;

@@ -41,11 +41,25 @@ def load_lightning_checkpoint(ckpt, use_ema=True):
     if not state:
         raise KeyError("checkpoint state_dict has no 'dnn.*' tensors")
     name = hp.get("backbone", "ncsnpp_v2")
-    if name not in VARIANTS:
-        raise KeyError(f"backbone {name!r} is not one of {sorted(VARIANTS)}")
+    from .tfgridnet import VARIANTS as TFG_VARIANTS, param_shapes as tfg_param_shapes
+    if name not in VARIANTS and name not in TFG_VARIANTS:
+        raise KeyError(f"backbone {name!r} is not one of {sorted(VARIANTS) + sorted(TFG_VARIANTS)}")
     ema = ckpt.get("ema") if use_ema else None
     if ema is not None and ema.get("shadow_params") is not None:
-        state = ema_state_dict(Spec(**VARIANTS[name]), ema["shadow_params"])
+        if name in TFG_VARIANTS:
+            # TF-GridNet: parameters() order = state-dict order (no buffers); the EMA tracks the trainable ones, i.e. all but
+            # the fixed Fourier frequencies get_time_emb.W (requires_grad=False, layerspp.py:34), which stay as stored
+            shapes = tfg_param_shapes(**TFG_VARIANTS[name])
+            order = [k for k in shapes if k != "get_time_emb.W"]
+            sp = ema["shadow_params"]
+            if len(sp) != len(order):
+                raise ValueError(f"EMA holds {len(sp)} tensors, the backbone has {len(order)} trainable parameters")
+            for k, v in zip(order, sp):
+                if tuple(v.shape) != tuple(shapes[k]):
+                    raise ValueError(f"EMA tensor for {k}: shape {tuple(v.shape)} != expected {tuple(shapes[k])}")
+                state[k] = v
+        else:
+            state = ema_state_dict(Spec(**VARIANTS[name]), ema["shadow_params"])
     return hp, state
 
 

@@ -138,8 +138,9 @@ class HipTFGridNet:
             raise RuntimeError("HipTFGridNet needs a HIP device (torch.cuda.is_available() is False); there is no CPU fallback")
         if emb_hs != 1 or n_srcs != 1 or n_imics != 2:
             raise NotImplementedError("TF-GridNet here: emb_hs = 1, n_srcs = 1, n_imics = 2 (the registered variants)")
-        if dtype != torch.float32:
-            raise NotImplementedError("TF-GridNet runs in f32 only")
+        # (the drivers pass their storage dtype - bf16 by default - to whatever backbone the checkpoint names: this one
+        # computes in f32 whatever it is asked for)
+        dtype = torch.float32
         self.lib = hip.lib()
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.dtype = dtype

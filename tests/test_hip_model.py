@@ -264,6 +264,34 @@ def test_infer_folder_batched(tmp_path):
         assert sr == 16000 and e.shape == (n,) and np.isfinite(e).all()
 
 
+def test_infer_driver_with_tfgridnet_checkpoint(tmp_path):
+    """The drivers take whatever backbone the checkpoint names (infer_folder.py:74-77): a TF-GridNet checkpoint (no
+    spectrogram padding for this family, infer_folder.py:83-88) runs end to end, one file and batched."""
+    from fdbm_amd import infer
+    from fdbm_amd import tfgridnet as tg
+    name = "tfgridnet_4l32c80"
+    sd = {k: T(v) for k, v in tg.fill_state(tg.param_shapes(**tg.VARIANTS[name])).items()}
+    ckpt = tmp_path / "tfg.ckpt"
+    raw = {k: T(v) for k, v in tg.fill_state(tg.param_shapes(**tg.VARIANTS[name]), seed=5).items()}
+    raw["get_time_emb.W"] = sd["get_time_emb.W"]                    # (fixed, not tracked by the EMA)
+    torch.save({"state_dict": {"dnn." + k: v for k, v in raw.items()},
+                "hyper_parameters": dict(backbone=name, bridge="fm", noise_schedule="ot", n_fft=512, hop_length=256,
+                                         window="sqrthann", spec_factor=0.15, spec_abs_exponent=0.5, normalize="noisy"),
+                "ema": {"shadow_params": [sd[k] for k in sd if k != "get_time_emb.W"]}}, ckpt)
+    from fdbm_amd.checkpoint import load_lightning_checkpoint
+    _, st = load_lightning_checkpoint(str(ckpt))
+    assert all(torch.equal(st[k], sd[k]) for k in sd)               # the EMA weights are the ones evaluated
+    rng = np.random.default_rng(2)
+    waves = [(0.2 * rng.standard_normal(n)).astype(np.float32) for n in (6000, 6000, 9000)]
+    enh = infer.Enhancer(str(ckpt), device=DEV, N=2)
+    assert enh.pad_mode is None
+    one = enh(waves[0][None])
+    assert one.shape == (1, 6000) and np.isfinite(one).all()
+    many = enh.enhance_many(waves, batch=2)
+    assert [m.shape for m in many] == [(1, 6000), (1, 6000), (1, 9000)] and all(np.isfinite(m).all() for m in many)
+    assert enh.batch_shapes[0][0] == 1 and enh.batch_shapes[1][0] == 2          # the 9000-sample file alone, then the two 6000s
+
+
 def enh_row_shape(enh, n_samples):
     """[1, F, Tpad] of one row's padded spectrogram for a waveform of n_samples (as spec_forward_padded gives it)."""
     y = torch.zeros(1, n_samples, device=DEV)

@@ -16,7 +16,7 @@ Workload at every N (weak scaling): BASELINE.json configs[1] per rank - one synt
 bf16 storage + fp32 accumulate.  --batch 64 gives configs[2].
 
 Rank 0 prints ONE JSON line.  `roofline` prices the convolution kernel that carries most of the
-algorithmic flops (conv_ring_kernel, MFMA-bound, 65 % of them) from HIP-event timings of its launches
+algorithmic flops (conv_ring_kernel<R=16>, MFMA-bound: 57 % of them at batch 1, 97 % at batch 64) from HIP-event timings of its launches
 in one eager forward, lists every convolution kernel family the same way (`families`) and carries
 the HBM bytes per launch measured offline with rocprofv3 PMC passes (profiles/r0*/..pmc_traffic..json);
 `cpu_baseline` times the CPU oracle (a port, oracle/) on a bounded sample on the host cores.

@@ -309,8 +309,7 @@ def test_sampler_ode_int(golden):
         kernel) reproduces the CPU oracle;
     (2) with the HIP backbone it runs and stays finite.  Values are not compared there: adaptive
         step accept/reject decisions on the random-weight network turn 1e-5 differences into O(1)
-        ones (the CPU oracle on another CPU already lands 1.5e-2 from the reference's result,
-        tools/dbg_odeint.py), and for sb the flow at t = 1 has weights of +-3.3e7 that cancel in
+        ones (the CPU oracle on another CPU already lands 1.5e-2 from the reference's result), and for sb the flow at t = 1 has weights of +-3.3e7 that cancel in
         fp32."""
     from oracle import sampler as osamp
     g = golden("samplers")

@@ -110,7 +110,6 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
   const int64_t img = (int64_t)b * H * W;
   const int y0 = (tile0 / tiles_x) * R, x0 = (tile0 % tiles_x) * 16;        // the first tile (patch 0 by all threads)
 
-  if (p.stat_out && tid < 64) s_stat[tid] = 0.0;
 
   // segment table in scalar registers, read from the kernel argument ONCE: a scalar load inside the k-loop shares
   // the LDS reads' counter (lgkmcnt) and, returning out of order, turns every counted wait of the loop into a
@@ -742,31 +741,24 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
   }
   RSTAMP(21, 0);
   if (do_stat) {
+    // straight to the global unit statistics, one fp64 atomic pair per (wave, 4-channel unit): through an LDS stage and
+    // the boundary barrier the adds were issued as the very last thing of the launch and their round trip (~2 us) sat
+    // behind every workgroup's last store
+    double* srow = p.stat_out + ((int64_t)b * p.stat_nsplit + tile % p.stat_nsplit) * p.stat_G * 2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int n = n0 + wn * 64 + j * 16 + fk_e * 4;
       const float r1 = row16_sum(a1[j]), r2 = row16_sum(a2[j]);
       if (frow_e == 0 && n < Cout) {
-        atomicAdd(&s_stat[((n - n0) / scpg) * 2], (double)r1);
-        atomicAdd(&s_stat[((n - n0) / scpg) * 2 + 1], (double)r2);
+        atomicAdd(srow + (n / scpg) * 2, (double)r1);
+        atomicAdd(srow + (n / scpg) * 2 + 1, (double)r2);
       }
     }
   }
-  // tile boundary: the producers have put the next tile's first patch and weight tile 0 into LDS; every wave's
-  // statistics are in s_stat
+  // tile boundary: the producers have put the next tile's first patch and weight tile 0 into LDS
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_sched_barrier(0);
-  if (do_stat) {
-    const int g0 = n0 / scpg;
-    const int ng = min(p.stat_G - g0, (128 + scpg - 1) / scpg);
-    if (tid < ng * 2) {
-      const int k = tid & 1, g = g0 + (tid >> 1);
-      atomicAdd(p.stat_out + (((int64_t)b * p.stat_nsplit + tile % p.stat_nsplit) * p.stat_G + g) * 2 + k,
-                s_stat[(g - g0) * 2 + k]);
-      s_stat[(g - g0) * 2 + k] = 0.0;           // for the next tile (its atomics come a whole tile later)
-    }
-  }
   }     // tiles
   __builtin_amdgcn_s_setprio(0);
   RSTAMP(22, 0);

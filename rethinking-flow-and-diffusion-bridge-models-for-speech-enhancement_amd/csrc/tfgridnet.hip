@@ -184,14 +184,35 @@ __global__ void __launch_bounds__(256) tfg_gemm(const GemmArgs g) {
   const int wr = n0 + lr;
   const float* wrow = wr < g.N ? W + (int64_t)wr * g.K : nullptr;
   const int fr = lane & 15, fk = lane >> 4;
+  // software pipeline: the next k-step's operands are requested into registers before the current one is multiplied
+  // (with the loads inside the step every one of the K / 16 steps waited a full memory latency); 16-byte loads where
+  // the row starts and K allow it
+  const bool vecA = ((g.lda | g.K) & 3) == 0 && (g.seq_stride & 3) == 0 && (g.sA & 3) == 0;
+  const bool vecW = (g.K & 3) == 0 && (g.sW & 3) == 0;
+  float ra[4], rw[4];
+  auto fetch = [&](int k0) __attribute__((always_inline)) {
+    const int k = k0 + lk;
+    if (arow && vecA && k < g.K) {
+      const float4 v = *reinterpret_cast<const float4*>(arow + k);
+      ra[0] = v.x; ra[1] = v.y; ra[2] = v.z; ra[3] = v.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ra[j] = (arow && k + j < g.K) ? arow[k + j] : 0.f;
+    }
+    if (wrow && vecW && k < g.K) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + k);
+      rw[0] = v.x; rw[1] = v.y; rw[2] = v.z; rw[3] = v.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rw[j] = (wrow && k + j < g.K) ? wrow[k + j] : 0.f;
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < g.K; k0 += 16) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int k = k0 + lk + j;
-      As[lk + j][lr] = (arow && k < g.K) ? arow[k] : 0.f;
-      Ws[lk + j][lr] = (wrow && k < g.K) ? wrow[k] : 0.f;
-    }
+    for (int j = 0; j < 4; ++j) { As[lk + j][lr] = ra[j]; Ws[lk + j][lr] = rw[j]; }
     __syncthreads();
+    if (k0 + 16 < g.K) fetch(k0 + 16);
 #pragma unroll
     for (int kg = 0; kg < 4; ++kg) {
       float wv[2], av[2];

@@ -14,6 +14,7 @@
 namespace {
 
 constexpr int TFG_MAX_LAYERS = 8;
+constexpr int TFG_SEQ_CHUNK = 1024;     // sequences per pass of the recurrent path (bounds the workspace)
 
 // ---- small elementwise / layout kernels ---------------------------------------------------------------------------
 // x, y complex64 [B][1][F][T] -> in [B][T][F][4] = (x.re, x.im, y.re, y.im)   (tfgridnet.py:199, 219)
@@ -490,7 +491,11 @@ static TfgWs tfg_ws(const fdbm_tfgridnet_desc& d, int B, int F, int T) {
   const int C = d.emb_dim, H = d.hidden, ks = d.emb_ks, nh = d.n_head, E = d.qk_channels, Dv = C / nh, olp = ks - 1;
   const int64_t Tp = T + 2 * olp, Qp = F + 2 * olp;
   const int64_t px = (int64_t)B * T * F, pxp = (int64_t)B * Tp * Qp;
-  const int64_t nseq = B * (Tp > Qp ? Tp : Qp), Lmax = (Tp > Qp ? Tp : Qp) - olp;
+  // the recurrent path runs over chunks of at most TFG_SEQ_CHUNK sequences: the gate pre-activations of ALL sequences of a
+  // batch-64 evaluation would be 14 GB
+  int64_t nseq = B * (Tp > Qp ? Tp : Qp);
+  if (nseq > TFG_SEQ_CHUNK) nseq = TFG_SEQ_CHUNK;
+  const int64_t Lmax = (Tp > Qp ? Tp : Qp) - olp;
   TfgWs w;
   int64_t o = 0;
   auto take = [&](int64_t n) { const int64_t r = o; o += (n + 63) & ~(int64_t)63; return r; };
@@ -579,19 +584,23 @@ extern "C" int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* c, const void* x, cons
       const int L = Sl - olp;
       const int64_t nseq = (int64_t)B * A;
       tfg_ln_rows<<<grid_for(nseq * Sl), 256, 0, st>>>(n1, src, wt + b.ln_g[r], wt + b.ln_b[r], nullptr, nullptr, d.eps, nseq * Sl, C);
-      // unfold + W_ih for both directions: rows = windows of ks*C floats at stride C
-      if (tfg_gemm_launch(st, G, n1, wt + b.win[r], wt + b.bin[r], nullptr, nseq * L, 8 * H, ks * C, L, (int64_t)Sl * C, C,
-                          (int64_t)L * 8 * H, 8 * H)) return 1;
-      FDBM_CHECK(fdbm_memset_zero(hbuf, (((nseq * (L + 2 * olp) * 2 * H + (int64_t)ks * 2 * H) * 4 + 15) / 16) * 16, st) == 0, "fdbm_tfgridnet_forward: memset failed");
-      const dim3 lgrid((unsigned)((nseq + 1) / 2), 2);
-      if (H <= 80) tfg_lstm<80><<<lgrid, 320, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)nseq, L, H, olp);
-      else if (H <= 100) tfg_lstm<100><<<lgrid, 400, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)nseq, L, H, olp);
-      else tfg_lstm<128><<<lgrid, 512, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)nseq, L, H, olp);
-      FDBM_LAUNCH_CHECK("fdbm_tfgridnet_forward(lstm)");
-      // ConvTranspose1d(2H -> C, ks) + bias + residual: rows = windows of ks*2H floats of the zero-bordered sequence buffer
       float* dst = r == 0 ? x2 : x3;
-      if (tfg_gemm_launch(st, dst, hbuf, wt + b.wdec[r], wt + b.bdec[r], src, nseq * Sl, C, ks * 2 * H, Sl,
-                          (int64_t)(L + 2 * olp) * 2 * H, 2 * H, (int64_t)Sl * C, C)) return 1;
+      for (int64_t s0 = 0; s0 < nseq; s0 += TFG_SEQ_CHUNK) {
+        const int64_t ns = nseq - s0 < TFG_SEQ_CHUNK ? nseq - s0 : TFG_SEQ_CHUNK;
+        // unfold + W_ih for both directions: rows = windows of ks*C floats at stride C
+        if (tfg_gemm_launch(st, G, n1 + s0 * Sl * C, wt + b.win[r], wt + b.bin[r], nullptr, ns * L, 8 * H, ks * C, L, (int64_t)Sl * C, C,
+                            (int64_t)L * 8 * H, 8 * H)) return 1;
+        FDBM_CHECK(fdbm_memset_zero(hbuf, (((ns * (L + 2 * olp) * 2 * H + (int64_t)ks * 2 * H) * 4 + 15) / 16) * 16, st) == 0,
+                   "fdbm_tfgridnet_forward: memset failed");
+        const dim3 lgrid((unsigned)((ns + 1) / 2), 2);
+        if (H <= 80) tfg_lstm<80><<<lgrid, 320, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)ns, L, H, olp);
+        else if (H <= 100) tfg_lstm<100><<<lgrid, 400, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)ns, L, H, olp);
+        else tfg_lstm<128><<<lgrid, 512, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)ns, L, H, olp);
+        FDBM_LAUNCH_CHECK("fdbm_tfgridnet_forward(lstm)");
+        // ConvTranspose1d(2H -> C, ks) + bias + residual: rows = windows of ks*2H floats of the zero-bordered sequence buffer
+        if (tfg_gemm_launch(st, dst + s0 * Sl * C, hbuf, wt + b.wdec[r], wt + b.bdec[r], src + s0 * Sl * C, ns * Sl, C, ks * 2 * H, Sl,
+                            (int64_t)(L + 2 * olp) * 2 * H, 2 * H, (int64_t)Sl * C, C)) return 1;
+      }
       if (r == 0) {
         tfg_transpose_crop<<<grid_for(pxp * C / 4), 256, 0, st>>>(xt, x2, B, Tp, Qp, C, 0, 0);       // [B][Qp][Tp][C]
         src = xt;

@@ -352,3 +352,20 @@ def test_tfgridnet_vs_reference(golden, name):
     br = fdbm_amd.Bridge("fm", N=2, sampler_type="ode_ei")
     s = br.sampler(m, y, generator=torch.Generator().manual_seed(3))
     assert s.shape == y.shape and torch.isfinite(torch.view_as_real(s)).all()
+
+
+def test_tfgridnet_batch_rows_and_sequence_chunks(golden):
+    """Rows of a batch are independent evaluations, also where the recurrent path runs in several passes over chunks of
+    sequences (4 x 263 inter-frame sequences > the 1 024 of one pass, with a ragged last chunk)."""
+    g = golden("tfgridnet_4l32c80")
+    m = fdbm_amd.BackboneRegistry.get_by_name("tfgridnet_4l32c80")(device=DEV)
+    x2, y2 = T(g["x"]).to(DEV), T(g["y"]).to(DEV)                 # [2,1,257,24]
+    x = torch.cat([x2, 0.5 * torch.roll(x2, 5, dims=-1)], 0)
+    y = torch.cat([y2, 0.8 * torch.roll(y2, 3, dims=-2)], 0)
+    t = torch.tensor([0.63, 0.21, 0.9, 0.05])
+    out = m(x, y, t)
+    for b in range(4):
+        one = m(x[b:b + 1], y[b:b + 1], t[b:b + 1])
+        d = (out[b:b + 1] - one).abs().max().item()
+        assert d <= 2e-5 * max(1.0, one.abs().max().item()), (b, d)
+    assert (out[:2].cpu() - T(g["out"])).abs().max().item() < 3e-3

@@ -360,3 +360,28 @@ def test_fail_loudly_on_cpu_tensors():
     x = torch.zeros(1, 1, 257, 64, dtype=torch.complex64)
     with pytest.raises(RuntimeError):
         m(x, x, torch.ones(1))
+
+
+@pytest.mark.parametrize("sched", ["ve", "vp", "gmax"])
+def test_pc_sampler_other_schedules_batch2(golden, sched):
+    """SURVEY 8(f4), second half: the predictor-corrector sampler under the ve / vp / gmax schedules of the Schroedinger
+    bridge at B > 1 - per-sample [B] weights (the reference's own broadcast is only right for B = 1, bridge.py:287-306).
+    The captured graph, the eager loop and the CPU oracle (oracle/sampler.py with the oracle backbone) agree on a
+    two-row batch with the same host-drawn noise."""
+    from oracle import sampler as osamp
+    from oracle import ncsnpp as onet
+    g = golden("samplers")
+    y1 = T(g["mini64_y"])
+    y = torch.cat([y1, 0.8 * torch.roll(y1, 2, dims=-1)], 0)
+    hp = MINI64
+    sd = fill_state_dict(Spec(**hp).param_shapes(), seed=0)
+    cpu_net = onet.Model(sd, hp)
+    br = fdbm_amd.Bridge("sb", N=3, noise_schedule=sched, sampler_type="pc")
+    kw = dict(predictor_name="euler_maruyama", corrector_name="ald", corrector_steps=1, snr=0.4, denoise=True)
+    outs = [br.sampler(net("mini64"), y.to(DEV), generator=torch.Generator().manual_seed(77), use_graph=ug, **kw).cpu()
+            for ug in (True, False)]
+    ref = osamp.Sampler("sb", N=3, noise_schedule=sched).pc(cpu_net, y, torch.Generator().manual_seed(77), corrector="ald",
+                                                             snr=0.4, corrector_steps=1, denoise=True)
+    scale = max(1.0, ref.abs().max().item())
+    assert (outs[0] - outs[1]).abs().max().item() < 2e-4 * scale, sched
+    assert (outs[1] - ref).abs().max().item() < 5e-4 * scale, (sched, (outs[1] - ref).abs().max().item())

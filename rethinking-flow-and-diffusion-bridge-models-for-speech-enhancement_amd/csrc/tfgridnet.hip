@@ -117,21 +117,39 @@ __global__ void tfg_gn_temb_pad(float* __restrict__ out, const float* __restrict
 __global__ void tfg_ln_rows(float* __restrict__ out, const float* __restrict__ in, const float* __restrict__ gamma,
                             const float* __restrict__ beta, const float* __restrict__ prelu, const float* __restrict__ res,
                             float eps, int64_t rows, int C) {
+  // one row per thread, the row held in registers (C <= 64: 16-byte loads, one pass over memory)
+  const int C4 = C >> 2;
+  const float a = prelu ? prelu[0] : 1.f;
   for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
-    const float* p = in + r * C;
-    const float a = prelu ? prelu[0] : 1.f;
+    const float4* p = reinterpret_cast<const float4*>(in + r * C);
+    float4 v[16];
     float s = 0.f;
-    for (int c = 0; c < C; ++c) { float v = p[c]; v = (prelu && v < 0.f) ? a * v : v; s += v; }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < C4) {
+        float4 x = p[c];
+        if (prelu) { x.x = x.x < 0.f ? a * x.x : x.x; x.y = x.y < 0.f ? a * x.y : x.y; x.z = x.z < 0.f ? a * x.z : x.z; x.w = x.w < 0.f ? a * x.w : x.w; }
+        v[c] = x;
+        s += (x.x + x.y) + (x.z + x.w);
+      }
     const float mean = s / C;
     float q = 0.f;
-    for (int c = 0; c < C; ++c) { float v = p[c]; v = (prelu && v < 0.f) ? a * v : v; const float d = v - mean; q += d * d; }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < C4) {
+        const float d0 = v[c].x - mean, d1 = v[c].y - mean, d2 = v[c].z - mean, d3 = v[c].w - mean;
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+      }
     const float rstd = 1.f / sqrtf(q / C + eps);
-    for (int c = 0; c < C; ++c) {
-      float v = p[c]; v = (prelu && v < 0.f) ? a * v : v;
-      float o = (v - mean) * rstd * gamma[c] + beta[c];
-      if (res) o += res[r * C + c];
-      out[r * C + c] = o;
-    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < C4) {
+        const float4 g = reinterpret_cast<const float4*>(gamma)[c], bt = reinterpret_cast<const float4*>(beta)[c];
+        float4 o = {(v[c].x - mean) * rstd * g.x + bt.x, (v[c].y - mean) * rstd * g.y + bt.y,
+                    (v[c].z - mean) * rstd * g.z + bt.z, (v[c].w - mean) * rstd * g.w + bt.w};
+        if (res) { const float4 rr = reinterpret_cast<const float4*>(res + r * C)[c]; o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+        reinterpret_cast<float4*>(out + r * C)[c] = o;
+      }
   }
 }
 

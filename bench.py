@@ -399,6 +399,15 @@ def main():
                     extras[f"config4_{tag}_n100_b16_f16_rtf"] = 16 * CLIP_SECONDS / dt
                     extras[f"config4_{tag}_n100_b16_f16_tflops"] = 16 * evals * flops_fwd / dt / 1e12
                 del hp16
+            if args.batch == 1 and args.backbone == "ncsnpp_v2" and args.dtype == "bf16":
+                # the reference's other backbone family on the same clip: TF-GridNet (f32, eager sampler, fm/ot N = 30)
+                for name in ("tfgridnet_5l32c100", "tfgridnet_4l32c80"):
+                    hpt = HotPath(dev, torch.float32, args.N, 1, backbone=name, bridge="fm", schedule="ot")
+                    w1 = wave[:1]
+                    hpt.enhance(w1); torch.cuda.synchronize()
+                    t1 = time.perf_counter(); hpt.enhance(w1); torch.cuda.synchronize()
+                    extras[f"{name}_f32_rtf_b1"] = CLIP_SECONDS / (time.perf_counter() - t1)
+                    del hpt
         except Exception as e:       # side measurements must never kill the headline line
             extras["error"] = repr(e)
         result["extras"] = extras

@@ -269,13 +269,13 @@ __global__ void __launch_bounds__(256) tfg_gemm(const GemmArgs g) {
 // One workgroup = one (sequence, direction); thread r < 4H owns gate row r of W_hh (H floats in registers).
 // G [nseq][L][8H]: input pre-activations (fwd gates | bwd gates, biases included); hout [nseq][L + 2*hp][2H] (the
 // zero border of hp entries is what ConvTranspose1d reads; written elsewhere, once).
-template <int HMAX>
+template <int HMAX, int NS>
 __global__ void __launch_bounds__(4 * HMAX) tfg_lstm(float* __restrict__ hout, const float* __restrict__ G,
                                                      const float* __restrict__ whh_f, const float* __restrict__ whh_b,
                                                      int nseq, int L, int H, int hp) {
-  // TWO sequences per workgroup share the register-resident W_hh rows: 263 sequences x 2 directions are then 264
-  // workgroups - one round over the 256 CUs (one 7-wave workgroup with 134 VGPRs fits a CU) instead of three.
-  constexpr int NS = 2;
+  // NS sequences per workgroup share the register-resident W_hh rows (one 7-wave workgroup with ~136 VGPRs fits a CU, so
+  // the launch runs in ceil(workgroups / 256) rounds): the host picks NS in 1..4 to minimise rounds x step time - at batch 1
+  // (263 sequences x 2 directions) NS = 3 gives 176 workgroups = ONE round where NS = 2 gave 264 = two.
   __shared__ __attribute__((aligned(16))) float s_h[NS][HMAX];
   __shared__ float s_g[NS][4 * HMAX];
   const int seq0 = blockIdx.x * NS, dir = blockIdx.y;
@@ -610,10 +610,26 @@ extern "C" int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* c, const void* x, cons
                             (int64_t)L * 8 * H, 8 * H)) return 1;
         FDBM_CHECK(fdbm_memset_zero(hbuf, (((ns * (L + 2 * olp) * 2 * H + (int64_t)ks * 2 * H) * 4 + 15) / 16) * 16, st) == 0,
                    "fdbm_tfgridnet_forward: memset failed");
-        const dim3 lgrid((unsigned)((ns + 1) / 2), 2);
-        if (H <= 80) tfg_lstm<80><<<lgrid, 320, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)ns, L, H, olp);
-        else if (H <= 100) tfg_lstm<100><<<lgrid, 400, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)ns, L, H, olp);
-        else tfg_lstm<128><<<lgrid, 512, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)ns, L, H, olp);
+        // sequences per workgroup: rounds over the 256 CUs x measured step time (~0.70 + 0.37 NS us)
+        int NS = 1;
+        double best = 1e30;
+        for (int c2 = 1; c2 <= 4; ++c2) {
+          const int64_t wgs = 2 * ((ns + c2 - 1) / c2);
+          const int64_t slots = H <= 80 ? 512 : 256;          // (H = 80: 120 VGPRs, two 5-wave workgroups share a CU)
+          const double cost = (double)((wgs + slots - 1) / slots) * (0.70 + 0.37 * c2);
+          if (cost < best - 1e-9) { best = cost; NS = c2; }
+        }
+        const dim3 lgrid((unsigned)((ns + NS - 1) / NS), 2);
+#define TFG_LSTM_LAUNCH(HM, N_)                                                                                      \
+  tfg_lstm<HM, N_><<<lgrid, 4 * HM, 0, st>>>(hbuf, G, wt + b.whh_f[r], wt + b.whh_b[r], (int)ns, L, H, olp)
+#define TFG_LSTM_NS(HM)                                                                                              \
+  do {                                                                                                               \
+    if (NS == 1) TFG_LSTM_LAUNCH(HM, 1); else if (NS == 2) TFG_LSTM_LAUNCH(HM, 2);                                   \
+    else if (NS == 3) TFG_LSTM_LAUNCH(HM, 3); else TFG_LSTM_LAUNCH(HM, 4);                                           \
+  } while (0)
+        if (H <= 80) TFG_LSTM_NS(80); else if (H <= 100) TFG_LSTM_NS(100); else TFG_LSTM_NS(128);
+#undef TFG_LSTM_NS
+#undef TFG_LSTM_LAUNCH
         FDBM_LAUNCH_CHECK("fdbm_tfgridnet_forward(lstm)");
         // ConvTranspose1d(2H -> C, ks) + bias + residual: rows = windows of ks*2H floats of the zero-bordered sequence buffer
         if (tfg_gemm_launch(st, dst + s0 * Sl * C, hbuf, wt + b.wdec[r], wt + b.bdec[r], src + s0 * Sl * C, ns * Sl, C, ks * 2 * H, Sl,

@@ -331,7 +331,7 @@ def main():
     achieved = f_dom / t_dom / 1e12
     traffic = None
     fam_name = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel", 3: "conv_ring_kernel<R=16>",
-                4: "conv_ring_kernel<R=8>"}
+                4: "conv_ring_kernel<R=8>", 5: "conv_head_kernel"}
     pmc = os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_b{args.batch}_bf16.json")
     if args.dtype == "bf16" and os.path.exists(pmc):
         try:        # measured offline with rocprofv3 --pmc (tools/pmc_workload.py), bytes per launch

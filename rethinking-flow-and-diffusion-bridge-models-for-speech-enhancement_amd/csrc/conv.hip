@@ -511,7 +511,7 @@ static int conv_policy() {
   return g_policy;
 }
 // 0 = tap-outer implicit GEMM, 1 = halo-patch, 2 = wave-per-tap, 3 = producer/consumer ring on 16 x 16 pixel tiles,
-// 4 = the same on 8 x 16 pixel tiles; -1 before the first call.
+// 4 = the same on 8 x 16 pixel tiles, 5 = the 4-channel head kernel; -1 before the first call.
 // For measurement harnesses (bench.py prices each kernel family against its roofline).
 extern "C" int fdbm_conv_last_kind(void) { return g_last_kind; }
 
@@ -555,6 +555,8 @@ int fdbm_launch_conv_tap(const ConvParams& p, int dt_in, int dt_out, int tw, int
 int fdbm_launch_conv_ring(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                  // conv_ring.hip
 bool fdbm_conv_ring_ok(const ConvParams& p, int rows);
 int fdbm_launch_conv_ring8(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                 // conv_ring8.hip
+int fdbm_launch_conv_head(const ConvParams& p, int dt_in, hipStream_t st);                               // conv_head.hip
+bool fdbm_conv_head_ok(const ConvParams& p);
 
 // Which kernel runs a conv of this shape: kind 1 = halo-patch 3x3 kernel (conv_patch.hip, tile
 // th x 16 pixels x 128 channels), kind 2 = wave-per-tap 3x3 kernel for small grids (conv_tap.hip,
@@ -719,6 +721,11 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
       g_last_kind = 4;
       return fdbm_launch_conv_ring8(p, a->dt_in, a->dt_out, st);
     }
+  }
+  if (kind == 1 && a->dt_in != FDBM_F32 && a->dt_out == FDBM_F32 && fdbm_conv_head_ok(p)) {
+    // the 4-channel f32 heads: all weights resident in LDS, workgroups walk tiles (conv_head.hip)
+    static const char* hoff = getenv("FDBM_CONV_HEAD");          // experiments: "0" = the 16-channel halo-patch tiles
+    if (!(hoff && hoff[0] == '0')) { g_last_kind = 5; return fdbm_launch_conv_head(p, a->dt_in, st); }
   }
   g_last_kind = kind;
   if (kind == 1) {

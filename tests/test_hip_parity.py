@@ -369,3 +369,23 @@ def test_tfgridnet_batch_rows_and_sequence_chunks(golden):
         d = (out[b:b + 1] - one).abs().max().item()
         assert d <= 2e-5 * max(1.0, one.abs().max().item()), (b, d)
     assert (out[:2].cpu() - T(g["out"])).abs().max().item() < 3e-3
+
+
+def test_tfgridnet_c_abi_error_paths():
+    """Error behaviour at the boundary: a weight blob of the wrong length is refused at creation, a workspace that is too
+    small is refused by the forward (status + message, nothing launched)."""
+    import ctypes
+    from fdbm_amd import hip
+    from fdbm_amd import tfgridnet as tg
+    L = hip.lib()
+    m = fdbm_amd.BackboneRegistry.get_by_name("tfgridnet_4l32c80")(device=DEV)
+    assert not L.fdbm_tfgridnet_create(ctypes.byref(m.desc), m.weights.data_ptr(), m.weights.numel() - 1)
+    assert b"weight blob" in L.fdbm_last_error()
+    x = torch.zeros(1, 1, 33, 12, dtype=torch.complex64, device=DEV)
+    logt = torch.zeros(1, device=DEV)
+    ws = torch.empty(1024, dtype=torch.uint8, device=DEV)
+    rc = L.fdbm_tfgridnet_forward(m.ctx, x.data_ptr(), x.data_ptr(), logt.data_ptr(), x.data_ptr(), 1, 33, 12,
+                                  ws.data_ptr(), ws.numel(), None, hip.stream_ptr())
+    assert rc != 0 and b"workspace too small" in L.fdbm_last_error()
+    out = m(x + 0.1, x + 0.2, torch.tensor([0.5]))              # the context is still usable
+    assert torch.isfinite(torch.view_as_real(out)).all()

@@ -108,3 +108,24 @@ def test_packed_blob_reproduces_the_oracle():
     assert out.shape == ref.shape
     err = (out - ref).abs().max().item()
     assert err < 5e-4 * max(1.0, ref.abs().max().item()), err
+
+
+def test_c_layout_matches_python_blob():
+    """Host-only entry points of the C ABI (no GPU needed): the blob length the library computes from an architecture
+    descriptor equals what pack_state writes, the workspace query is positive and grows with the batch, and descriptors
+    the kernels do not cover are refused with an error message."""
+    import ctypes
+    from fdbm_amd import hip
+    L = hip.lib()
+    for name, hp in tg.VARIANTS.items():
+        d = tg.Desc(hp["n_layers"], hp["emb_dim"], hp["lstm_hidden_units"], 4, 4, 2, 4, 2, 1e-5)
+        blob = tg.pack_state(tg.fill_state(tg.param_shapes(**hp)), **hp)
+        assert L.fdbm_tfgridnet_weights_count(ctypes.byref(d)) == blob.numel(), name
+        w1 = L.fdbm_tfgridnet_workspace_bytes(ctypes.byref(d), 1, 257, 256)
+        w4 = L.fdbm_tfgridnet_workspace_bytes(ctypes.byref(d), 4, 257, 256)
+        assert 0 < w1 < w4 < (64 << 30), (name, w1, w4)
+    bad = tg.Desc(5, 30, 100, 4, 4, 2, 4, 2, 1e-5)              # emb_dim not a multiple of 4
+    assert L.fdbm_tfgridnet_weights_count(ctypes.byref(bad)) == -1
+    assert b"unsupported" in L.fdbm_last_error()
+    assert L.fdbm_tfgridnet_workspace_bytes(ctypes.byref(bad), 1, 257, 256) == -1
+    assert not L.fdbm_tfgridnet_create(ctypes.byref(bad), None, 0)

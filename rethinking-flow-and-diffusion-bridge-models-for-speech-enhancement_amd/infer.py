@@ -19,11 +19,12 @@ GPUs get length-balanced shards of the file list (fdbm_amd.dist.shard_by_length)
 padded spectrogram length and runs the sampler on up to B rows at a time (Enhancer.enhance_many); every file still gets
 its own normalisation factor, STFT, padding, inverse transform and clip rule, so its result is the one-at-a-time result.
 
-Differences, all on the audio-file side (the image has neither soundfile / torchaudio nor librosa):
-WAV is read and written with scipy.io.wavfile (PCM 8/16/24/32-bit and float; output float32 like
-soundfile's default for float arrays would be 16-bit PCM - here float32 WAV, lossless), FLAC files are
-reported and skipped, and resampling uses scipy.signal.resample_poly (polyphase Kaiser FIR) instead of
-librosa's soxr - only for inputs that are not 16 kHz already.
+Differences, all on the audio-file side (the image has neither soundfile / torchaudio nor librosa): WAV is read and
+written with scipy.io.wavfile (PCM 8/16/24/32-bit and float; output float32 WAV, lossless, where soundfile's default for
+float arrays would be 16-bit PCM), FLAC is read by a decoder written from the format specification (fdbm_amd/flac.py:
+every subframe type, both CRCs and the MD5 signature verified; checked against a test encoder, no libFLAC here), and
+resampling uses scipy.signal.resample_poly (polyphase Kaiser FIR) instead of librosa's soxr - only for inputs that are
+not 16 kHz already.
 """
 import argparse
 import ast
@@ -64,6 +65,14 @@ def read_wav(path):
         x = x.astype(np.float32)
     x = x[None, :] if x.ndim == 1 else x.T
     return np.ascontiguousarray(x), int(sr)
+
+
+def read_audio(path):
+    """wav or flac (infer_folder.py:58-65,94 reads both through soundfile) -> (float32 [C, L], sample rate)."""
+    if path.lower().endswith(".flac"):
+        from .flac import read_flac
+        return read_flac(path)
+    return read_wav(path)
 
 
 def resample_to(x, sr, target=TARGET_SR):
@@ -204,9 +213,7 @@ def enhance_files(gpu_id, file_list, args, counter=None):
     done = 0
     for noisy_file in file_list:
         try:
-            if noisy_file.lower().endswith(".flac"):
-                raise RuntimeError("FLAC input needs an audio library this build does not have; convert to WAV")
-            y, sr = read_wav(noisy_file)
+            y, sr = read_audio(noisy_file)
             x_hat = enh(resample_to(y, sr))
             out = output_path(noisy_file, args)
             os.makedirs(dirname(out) or ".", exist_ok=True)
@@ -241,9 +248,7 @@ def enhance_files_batched(gpu_id, file_list, args, counter=None):
         names, waves = [], []
         for noisy_file in file_list[w0:w0 + win]:
             try:
-                if noisy_file.lower().endswith(".flac"):
-                    raise RuntimeError("FLAC input needs an audio library this build does not have; convert to WAV")
-                y, sr = read_wav(noisy_file)
+                y, sr = read_audio(noisy_file)
                 waves.append(resample_to(y, sr))
                 names.append(noisy_file)
             except Exception as e:
@@ -307,7 +312,7 @@ def enhance_single(args):
     """infer_single.py:60-106: one file, default output next to the input with an _enhanced suffix, clip to 0.5."""
     enh = Enhancer(args.ckpt, device=f"cuda:{int(args.device[0])}", N=args.N, sampler_type=args.sampler_type,
                    sampler_kwargs=args.sampler_kwargs, dtype=torch.float32 if args.fp32 else torch.bfloat16)
-    y, sr = read_wav(args.noisy_file)
+    y, sr = read_audio(args.noisy_file)
     x_hat = enh(resample_to(y, sr), clip=0.5)
     out = args.output_file
     if not out:

@@ -284,3 +284,63 @@ def test_shard_by_length_balances_and_covers():
             assert ls == sorted(ls, reverse=True)
         assert sh == shard_by_length(lengths, w)
     assert shard_by_length([], 4) == [[], [], [], []]
+
+
+def _flac_cases():
+    rng = np.random.default_rng(11)
+    t = np.arange(9000)
+    tone = (6000 * np.sin(2 * np.pi * 220 * t / 16000) + 500 * rng.standard_normal(t.size)).astype(np.int64)
+    stereo = np.stack([tone, (0.6 * tone + 300 * rng.standard_normal(t.size)).astype(np.int64)])
+    fixed = [(4096, ("fixed", o, p, e), "indep") for o, p, e in ((0, 0, False), (1, 2, False), (2, 3, True))] + \
+            [(1152, ("fixed", 3, 1, False), "indep"), (192, ("fixed", 4, 0, False), "indep"), (300, "verbatim", "indep")]
+    yield "mono16_fixed", tone[None], 16000, 16, fixed, {}
+    yield "mono16_lpc_variable", tone[None], 16000, 16, [(4096, ("lpc", 8, 12, 9, 2), "indep"), (4096, ("lpc", 1, 5, 3, 0), "indep"),
+                                                          (808, ("lpc", 32, 14, 10, 0), "indep")], dict(variable=True, rate_in_header="hz")
+    for st in ("ls", "rs", "ms"):
+        yield f"stereo16_{st}", stereo, 44100, 16, [(4096, ("fixed", 2, 2, False), st), (4096, ("lpc", 4, 10, 8, 1), st),
+                                                     (808, "verbatim", st)], {}
+    big = (tone * 200 + rng.integers(-100, 100, tone.size))                       # 24-bit range
+    yield "mono24_streaminfo_params", big[None], 48000, 24, [(2304, ("fixed", 2, 0, False), "indep")] * 3 + [(2088, ("lpc", 6, 15, 12, 0), "indep")], \
+        dict(rate_in_header="none", bps_in_header=False)
+    yield "mono8_khz", (tone // 64)[None], 32000, 8, [(576, ("fixed", 1, 0, False), "indep")] * 15 + [(360, "verbatim", "indep")], dict(rate_in_header="khz")
+    const = np.concatenate([np.full(256, 77), np.zeros(256, dtype=np.int64), (tone[:512] // 8) * 8])      # constant blocks, wasted bits
+    yield "mono16_constant_wasted", const[None], 22050, 16, [(256, "constant", "indep"), (256, "constant", "indep"),
+                                                              (512, ("fixed", 2, 1, False), "indep")], dict(rate_in_header="tens")
+
+
+@pytest.mark.parametrize("case", list(_flac_cases()), ids=lambda c: c[0])
+def test_flac_decoder(case):
+    """fdbm_amd/flac.py against the test encoder (tests/flac_encode.py, written from the same specification): every
+    subframe type, fixed orders 0-4, LPC orders 1-32, Rice partitions incl. escaped ones, wasted bits, the three stereo
+    decorrelations, fixed and variable blocking, every way a frame header can carry block size / sample rate / sample size -
+    bit-exact samples, both CRCs and the MD5 signature verified by the decoder."""
+    from fdbm_amd import flac
+    from flac_encode import encode
+    name, x, rate, bps, blocks, kw = case
+    data = encode(x, rate, bps, blocks, **kw)
+    y, r, b = flac.decode(data)
+    assert r == rate and b == bps and y.shape == x.shape and np.array_equal(y, x), name
+    # integrity checks bite: a flipped payload bit is caught by the frame CRC-16, a flipped header bit by the CRC-8
+    bad = bytearray(data)
+    bad[-5] ^= 0x10
+    with pytest.raises(flac.FlacError):
+        flac.decode(bytes(bad))
+    first_frame = data.index(b"\xff\xf8" if not kw.get("variable") else b"\xff\xf9", 4 + 4 + 34 + 12)
+    bad = bytearray(data)
+    bad[first_frame + 2] ^= 0x01
+    with pytest.raises(flac.FlacError):
+        flac.decode(bytes(bad))
+
+
+def test_flac_in_the_folder_driver(tmp_path):
+    """infer.read_audio takes .flac next to .wav (infer_folder.py:58-65,94)."""
+    from fdbm_amd import infer
+    from flac_encode import encode
+    rng = np.random.default_rng(3)
+    x = (8000 * np.sin(np.arange(5000) / 9.0) + 100 * rng.standard_normal(5000)).astype(np.int64)
+    p = tmp_path / "a.flac"
+    p.write_bytes(encode(x[None], 16000, 16, [(4096, ("fixed", 2, 2, False), "indep"), (904, ("lpc", 3, 9, 7, 0), "indep")]))
+    y, sr = infer.read_audio(str(p))
+    assert sr == 16000 and y.shape == (1, 5000) and y.dtype == np.float32
+    assert np.array_equal(y[0], (x / 32768.0).astype(np.float32))
+    assert str(p) in infer.get_audio_files(str(tmp_path))

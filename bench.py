@@ -361,7 +361,7 @@ def main():
         "forward_ms_eager": fwd_ms, "forward_ms_in_graph": 1e3 * elapsed / args.steps / args.N,
     }
 
-    if not args.no_extras:
+    if not args.no_extras and world == 1:        # side measurements belong to the single-GPU line
         extras = {}
         try:
             hp32 = HotPath(dev, torch.float32, args.N, 1, backbone=args.backbone)

@@ -351,20 +351,22 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
 
     // ---- prologue: weights 0..3 requested, weights 0 written; patch 0 by all threads -----------------------------
     RSTAMP(33, 256);
-    RSTAMP(34, 256);
-    if constexpr (GNP) conv_gn_table<512>(p, b, 1, s_gn, gnpad, s_mr, smem + PB);
-    RSTAMP(35, 256);
-    p0_store();
-    RING_WRITE_W(wa0, wa1, wa2, wa3, 0);
-    RING_LOAD_W(wa0, wa1, wa2, wa3);     // weights(3)
     {
-      // the patch of chunk 1 (clamped: of chunk 0 again where there is none) is requested now, a whole chunk ahead
+      // the patch of chunk 1 (clamped: of chunk 0 again where there is none) is requested HERE, a whole chunk ahead and in
+      // front of the GroupNorm table and patch 0: requested behind them, its items 0 and 1 - transformed in the first
+      // interval - were a full memory latency away (1.3 - 2 us of every launch, tools/ring_timeline.py)
       int s1 = 0, c1 = 1;
       if (c1 == sg_n0) { c1 = 0; s1 = 1; }
       if (s1 >= nseg) { s1 = 0; c1 = 0; }
       patch_request_begin(s1, c1);
       ring_static_for<0, NIT>([&](auto JJ) __attribute__((always_inline)) { load_item(JJ, false); });
     }
+    RSTAMP(34, 256);
+    if constexpr (GNP) conv_gn_table<512>(p, b, 1, s_gn, gnpad, s_mr, smem + PB);
+    RSTAMP(35, 256);
+    p0_store();
+    RING_WRITE_W(wa0, wa1, wa2, wa3, 0);
+    RING_LOAD_W(wa0, wa1, wa2, wa3);     // weights(3)
     RSTAMP(36, 256);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();       // tick(-1)
@@ -438,7 +440,13 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
           if constexpr (t == 0) { if (nreg) load_scale_shift(ns, nc); }
           ring_static_for<x0_, x1_>([&](auto JJ) __attribute__((always_inline)) { xform_item(JJ, nreg, w1); });
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifdef FDBM_STAMPS
+          if (ci < 2 && ti == tile0) RSTAMP(64 + 2 * (ci * 9 + t), 256);      // interval's own work done (before the tick)
+#endif
           __builtin_amdgcn_s_barrier();   // tick
+#ifdef FDBM_STAMPS
+          if (ci < 2 && ti == tile0) RSTAMP(65 + 2 * (ci * 9 + t), 256);      // tick passed
+#endif
         };
         interval(std::integral_constant<int, 0>{}); interval(std::integral_constant<int, 1>{});
         interval(std::integral_constant<int, 2>{}); interval(std::integral_constant<int, 3>{});

@@ -34,9 +34,12 @@ def run(B, cins, short, H=256, pol=11, cout=128, **feat):
         if s[i]:
             print(f"   P {pn.get(i, f'chunk {i - 38} done'):22s} {(s[i] - t0) * ns:9.0f} ns")
     if s[64]:
-        print("   P chunk 1 intervals: start | work done | waits done | tick passed (ns)")
-        for t in range(9):
-            print("     t=%d " % t + " ".join(f"{(s[64 + 4 * t + k] - t0) * ns:8.0f}" for k in range(4)))
+        print("   P intervals of chunks 0 and 1: own work done | tick passed (ns), and the interval's length")
+        prev = s[37]
+        for i in range(18):
+            a, b_ = s[64 + 2 * i], s[65 + 2 * i]
+            print(f"     chunk {i // 9} t={i % 9}: {(a - t0) * ns:8.0f} {(b_ - t0) * ns:8.0f}   work {(a - prev) * ns:6.0f}  wait {(b_ - a) * ns:6.0f}")
+            prev = b_
 
 
 if len(sys.argv) > 1 and sys.argv[1] == "b4":

@@ -257,13 +257,7 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
     };
 #pragma unroll
     for (int j = 0; j < NIT; ++j) { ppix[j] = ppix_of(j, tile0); ppixn[j] = ppix[j]; }
-#pragma unroll
-    for (int j = 0; j < NIT; ++j) {
-      const int row = (ptid >> 3) + 32 * j;
-      const int rr = min(row, PROWS - 1);
-      const int pc = rr % PC;
-      plds[j] = row * 128 + ((pchunk ^ ((pc >> 1) & 7)) << 4);
-    }
+    // (plds is filled in behind the first patch request, below: integer work that then covers the request's latency)
     int cy0 = y0, cx0 = x0;      // the current tile's origin (the tail's interior patches)
 
     // ---- patch staging of chunk (s, c) through registers
@@ -360,6 +354,13 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
       if (s1 >= nseg) { s1 = 0; c1 = 0; }
       patch_request_begin(s1, c1);
       ring_static_for<0, NIT>([&](auto JJ) __attribute__((always_inline)) { load_item(JJ, false); });
+    }
+#pragma unroll
+    for (int j = 0; j < NIT; ++j) {
+      const int row = (ptid >> 3) + 32 * j;
+      const int rr = min(row, PROWS - 1);
+      const int pc = rr % PC;
+      plds[j] = row * 128 + ((pchunk ^ ((pc >> 1) & 7)) << 4);
     }
     RSTAMP(34, 256);
     if constexpr (GNP) conv_gn_table<512>(p, b, 1, s_gn, gnpad, s_mr, smem + PB);

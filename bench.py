@@ -13,7 +13,8 @@ evaluations + 30 fused state updates, one HIP graph) -> inverse compression + iS
 renormalise [-> RCCL all-gather of the enhanced spectrograms when N > 1].
 Workload at every N (weak scaling): BASELINE.json configs[1] per rank - one synthetic
 4 s clip, ncsnpp_v2 (65.6 M parameters, deterministic synthetic weights), bridge sb/bb,
-bf16 storage + fp32 accumulate.  --batch 64 gives configs[2].
+bf16 storage + fp32 accumulate.  --batch 64 gives configs[2];
+--batch 16 --N 100 --dtype f16 --sampler sde_ei | pc gives configs[4] as the timed workload (the default run times both in `extras`).
 
 Rank 0 prints ONE JSON line.  `roofline` prices the convolution kernel that carries most of the
 algorithmic flops (conv_ring_kernel<R=16>, MFMA-bound: 57 % of them at batch 1, 97 % at batch 64) from HIP-event timings of its launches
@@ -63,22 +64,30 @@ def synth_clips(B, seed, device):
 class HotPath:
     """waveforms in HBM -> enhanced waveforms in HBM, everything through libfdbm_hip.so."""
 
-    def __init__(self, device, dtype, n_steps, batch, backbone="ncsnpp_v2", bridge="sb", schedule="bb"):
+    def __init__(self, device, dtype, n_steps, batch, backbone="ncsnpp_v2", bridge="sb", schedule="bb", sampler="ode_ei"):
         import fdbm_amd
         from fdbm_amd.frontend import SpecFrontend, pad_mode_for
         self.dev = device
         self.B = batch
         self.net = fdbm_amd.BackboneRegistry.get_by_name(backbone)(dtype=dtype, device=device)
         self.fe = SpecFrontend(n_fft=512, hop_length=256, window="sqrthann", device=device)   # config.yaml:35-38
-        self.bridge = fdbm_amd.Bridge(bridge, N=n_steps, sampler_type="ode_ei", noise_schedule=schedule)
+        self.bridge = fdbm_amd.Bridge(bridge, N=n_steps, sampler_type=sampler, noise_schedule=schedule)
         self.pad_mode = pad_mode_for(backbone)
         self.gen = torch.Generator().manual_seed(0)
+        self.kw = {}
+        if sampler != "ode_ei":
+            # BASELINE configs[4] (stochastic samplers): the per-step noise is resident in HBM like the clips (4 tensors,
+            # cycled), pc = euler_maruyama + ald, 1 corrector step, snr 0.5 (the reference's defaults, bridge.py:142-166)
+            z = [torch.view_as_complex(torch.randn(batch, 1, 257, 256, 2, device=device) * 0.7071) for _ in range(4)]
+            self.kw = dict(prior_noise=z[0], step_noise=lambda i: z[i % 4])
+            if sampler == "pc":
+                self.kw.update(predictor_name="euler_maruyama", corrector_name="ald", corrector_steps=1, snr=0.5, denoise=True)
 
     def enhance(self, wave):
         """infer_folder.py:102-121 per batch.  Returns (enhanced waveform, enhanced spectrogram)."""
         nf = self.fe.norm_factor(wave)                                    # max |y| per clip (fdbm_wave_norm_factor)
         Y = self.fe.spec_forward_padded(wave, self.pad_mode, norm=nf)     # y / nf fused into the STFT launch
-        X = self.bridge.sampler(self.net, Y, generator=self.gen)
+        X = self.bridge.sampler(self.net, Y, **self.kw) if self.kw else self.bridge.sampler(self.net, Y, generator=self.gen)
         x_hat = self.fe.to_audio(X[:, 0], wave.shape[-1], norm=nf, clip=0.95)   # * nf and the 0.95 clip rule fused
         return x_hat, X
 
@@ -196,7 +205,9 @@ def main():
                     help="configs[3]: a list of this many synthetic clips, strided over the ranks, enhanced in batches of "
                          "--batch; a step = the whole list once (strong scaling)")
     ap.add_argument("--N", type=int, default=30, help="sampler steps")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--sampler", default="ode_ei", choices=["ode_ei", "sde_ei", "pc"],
+                    help="ode_ei = configs[1..3]; sde_ei / pc with --batch 16 --N 100 --dtype f16 = configs[4]")
     ap.add_argument("--backbone", default="ncsnpp_v2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-forwards", type=int, default=2)
@@ -228,10 +239,11 @@ def main():
         assert comm_world == args.gpus, (comm_world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    evals_per_step = 2 * args.N if args.sampler == "pc" else args.N        # pc: predictor + 1 corrector evaluation
 
     from fdbm_amd import dist as fdist
-    hp = HotPath(dev, dtype, args.N, args.batch, backbone=args.backbone)
+    hp = HotPath(dev, dtype, args.N, args.batch, backbone=args.backbone, sampler=args.sampler)
     if args.clips:
         # configs[3]: the list is sharded by index (rank r takes clips r, r + W, ...: fdbm_amd.dist.shard_indices), every
         # rank walks its shard in batches of --batch (a ragged last batch is padded with its first clip and trimmed)
@@ -301,7 +313,7 @@ def main():
     F, T = 257, 256
     flops_fwd = hp.net.flops_per_forward(256, T)
     result = {
-        "metric": "real-time factor (audio-sec/wall-sec) @ N=30 steps, 16 kHz 4 s clips",
+        "metric": f"real-time factor (audio-sec/wall-sec) @ N={args.N} steps, 16 kHz 4 s clips",
         "value": rtf, "unit": "x real-time (audio-s / wall-s)",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
@@ -309,12 +321,12 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": (f"BASELINE configs[3]: {args.clips} synthetic 4 s 16 kHz clips sharded by index over the ranks, batches of {args.batch}, "
                                 if args.clips else
-                                f"BASELINE configs[{1 if args.batch == 1 else 2}]: {args.batch} synthetic 4 s 16 kHz clip(s) per rank per step, ") +
-                               f"{args.backbone} (deterministic synthetic weights), bridge sb/bb, ode_ei N={args.N}, "
+                                f"BASELINE configs[{4 if args.sampler != 'ode_ei' else 1 if args.batch == 1 else 2}]: {args.batch} synthetic 4 s 16 kHz clip(s) per rank per step, ") +
+                               f"{args.backbone} (deterministic synthetic weights), bridge sb/bb, {args.sampler} N={args.N}, "
                                "STFT 512/256 sqrt-Hann -> [257 x 256] complex spectrogram",
                    "batch_per_rank": args.batch, "sampler_steps": args.N, "rccl_world_size": comm_world,
                    "parallelism": f"dp{world} (utterance sharding, gather of spectrograms)"},
-        "whole_step_tflops": n_clips_step * args.N * flops_fwd / (elapsed / args.steps) / 1e12,
+        "whole_step_tflops": n_clips_step * evals_per_step * flops_fwd / (elapsed / args.steps) / 1e12,
     }
 
     # ---- roofline of the dominant kernel ---------------------------------------------------
@@ -323,7 +335,7 @@ def main():
     # all_conv = the same over every convolution launch (both kernels), i.e. incl. the
     # latency-bound small-map layers.
     times, flops, kinds, fwd_ms, prog = time_conv_launches(hp.net, args.batch, F, T)
-    peak = BF16_DENSE_PEAK_TFLOPS if args.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+    peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_DENSE_PEAK_TFLOPS       # f16 = bf16 dense MFMA peak
     dom = 3 if any(k == 3 for k in kinds) else 1
     sel = [i for i, k in enumerate(kinds) if k == dom] or list(range(len(times)))
     t_dom = sum(times[i] for i in sel) * 1e-3
@@ -358,7 +370,7 @@ def main():
         "families": families,
         "all_conv": {"achieved": sum(flops) / t_conv / 1e12, "frac": sum(flops) / t_conv / 1e12 / peak,
                      "launches_per_forward": len(times), "ms_per_forward": 1e3 * t_conv},
-        "forward_ms_eager": fwd_ms, "forward_ms_in_graph": 1e3 * elapsed / args.steps / args.N,
+        "forward_ms_eager": fwd_ms, "forward_ms_in_graph": 1e3 * elapsed / args.steps / evals_per_step,
     }
 
     if not args.no_extras and world == 1:        # side measurements belong to the single-GPU line

@@ -30,3 +30,12 @@ for B in ${@:-1 64}; do
   # raw traces are large: keep the summaries only
   rm -rf $O/stats_b$B $O/fetch_b$B $O/write_b$B $O/sq_b$B
 done
+# BASELINE configs[4] (fp16 storage, batch 16, N = 100): kernel stats of the stochastic and the predictor-corrector sampler
+if [ -n "$CONFIG4" ]; then
+  for S in sde_ei pc; do
+    rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4_$S -- python3 bench.py --batch 16 --N 100 --dtype f16 --sampler $S --steps 1 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_config4_${S}_under_rocprof.json 2> $O/stats_c4_$S.err
+    cp "$(find $O/stats_c4_$S -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_config4_${S}_b16_f16.csv
+    rm -rf $O/stats_c4_$S
+    echo "config4 $S done"
+  done
+fi

@@ -80,6 +80,9 @@ def check():
         dict(B=16, H=64, W=64, cins=[256, 256], cout=256, gn=True, stat=True),
         dict(B=8, H=128, W=128, cins=[128], cout=128, short=[128, 64]),
         dict(B=4, H=128, W=256, cins=[192], cout=128, gn=True, stat=True, short=[64]),
+        # 8 and 7 shortcut chunks (the tail's intervals are unrolled by 6)
+        dict(B=16, H=64, W=64, cins=[256], cout=256, short=[256, 256], gn=True, stat=True, res=True),
+        dict(B=16, H=64, W=64, cins=[128], cout=128, short=[256, 192]),
     ]
     # 8 x 16 pixel tiles (policy bit 16): the maps below a tile per CU, and the shapes above again
     cases8 = [
@@ -93,6 +96,8 @@ def check():
         dict(B=3, H=24, W=32, cins=[96], cout=256, short=[96], gn=True, stat=True, res=True),
         dict(B=8, H=128, W=128, cins=[128], cout=128, gn=True, stat=True, res=True, tbias=True),
         dict(B=4, H=64, W=64, cins=[256, 256], cout=256, gn=True, stat=True),
+        dict(B=2, H=64, W=64, cins=[256], cout=256, short=[256, 256], gn=True, stat=True, res=True),
+        dict(B=2, H=64, W=64, cins=[128], cout=128, short=[256, 192]),
     ]
     for kw, ringpol in [(c, 11) for c in cases] + [(c, 27) for c in cases8]:
         res = {}
@@ -118,8 +123,8 @@ def check():
 
 
 def bench(reps=30):
-    for B in (1, 4):
-        for cins, short in (([128], []), ([256], []), ([128], [128, 128]), ([128, 128], [])):
+    for B in (1, 4, 16):
+        for cins, short in (([128], []), ([256], []), ([128], [128, 128]), ([128, 128], []), ([128], [256, 256])):
             for feat in (dict(), dict(gn=True), dict(gn=True, stat=True, res=True)):
                 line = f"B{B} 256x256 {cins}+{short}->128 {feat}:"
                 for pol in (3, 11):

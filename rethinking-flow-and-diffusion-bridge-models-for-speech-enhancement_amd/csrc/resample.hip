@@ -135,6 +135,100 @@ __global__ void __launch_bounds__(256) resample2x_kernel(
   }
 }
 
+// 2 x 2 OUTPUT BLOCK per thread, for the fused GroupNorm+SiLU case on maps too large for the tiled kernel below: the
+// per-output kernel above evaluates the activation once per TAP (16 per output down, 4 per output up) and is VALU-bound
+// there (1.6 TB/s at batch 64).  A thread that forms the 2 x 2 outputs around one point shares the activated inputs between
+// them: down 6 x 6 inputs for 4 outputs (9 activations per output instead of 16), up 3 x 3 inputs for the 4 outputs
+// of one input pixel (2.25 instead of 4).  The inputs are streamed row by row and every output accumulates its taps in
+// the same order as above (rows outer, columns inner, same products): bit-identical results.
+// down: H, W multiples of 4.
+template <typename T, bool UP, bool PLAIN>
+__global__ void __launch_bounds__(256) resample2x_quad_kernel(
+    T* __restrict__ out_plain, T* __restrict__ out_act, const T* __restrict__ in,
+    const float* __restrict__ stats, int nsplit, double inv_count, float eps,
+    const float* __restrict__ gamma, const float* __restrict__ beta,
+    int H, int W, int C, int G, int chunks, int upg) {
+  constexpr int VW = DT<T>::vecw;
+  constexpr int NR = UP ? 3 : 6;               // input rows / columns of a block
+  extern __shared__ float s_ss[];               // [2][C] scale / shift
+  __shared__ double s_red[8 * 32 * 2];
+  const int b = blockIdx.y;
+  gn_scale_shift(s_ss, s_red, stats, nsplit, inv_count, eps, b, C, G, gamma, beta, upg);
+  const int OH = UP ? 2 * H : H / 2, OW = UP ? 2 * W : W / 2;
+  const int BH = OH / 2, BW = OW / 2;           // blocks of 2 x 2 outputs (up: one per input pixel)
+  const int nvec = C / VW;
+  const int64_t total = (int64_t)BH * BW * nvec;
+  const int64_t per = (total + chunks - 1) / chunks;
+  const int64_t i0 = blockIdx.x * per, i1 = min(total, i0 + per);
+  const T* img = in + (int64_t)b * H * W * C;
+  const float w4[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+    const int v = (int)(i % nvec);
+    const int64_t pb = i / nvec;
+    const int bx = (int)(pb % BW), by = (int)(pb / BW);
+    const int c = v * VW;
+    float sc[VW], sh[VW];
+#pragma unroll
+    for (int k = 0; k < VW; ++k) { sc[k] = s_ss[c + k]; sh[k] = s_ss[C + c + k]; }
+    float accp[2][2][VW], acca[2][2][VW];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < VW; ++k) accp[j][q][k] = acca[j][q][k] = 0.f;
+    const int y00 = UP ? by - 1 : 4 * by - 1, x00 = UP ? bx - 1 : 4 * bx - 1;     // first input row / column of the block
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int iy = y00 + r;
+      if (iy < 0 || iy >= H) continue;
+      float xr[NR][VW], xa[NR][VW];
+      bool okc[NR];
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int ix = x00 + q;
+        okc[q] = ix >= 0 && ix < W;
+        if (okc[q]) {
+          Vec16<T>::load(img + ((int64_t)iy * W + ix) * C + c, xr[q]);
+#pragma unroll
+          for (int k = 0; k < VW; ++k) xa[q][k] = silu_t<T>(xr[q][k] * sc[k] + sh[k]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        // output row 2 by + j: down taps k = r - 2 j in 0..3 (weight w4[k]); up rows {r = j, j + 1} with weights
+        // j == 0: {0.25, 0.75}, j == 1: {0.75, 0.25}
+        const int k = UP ? r - j : r - 2 * j;
+        if (k < 0 || k >= (UP ? 2 : 4)) continue;
+        const float wy = UP ? ((k == 0) == (j == 0) ? 0.25f : 0.75f) : w4[k];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+          for (int t = 0; t < (UP ? 2 : 4); ++t) {
+            const int cq = UP ? q + t : 2 * q + t;
+            if (!okc[cq]) continue;
+            const float wx = UP ? ((t == 0) == (q == 0) ? 0.25f : 0.75f) : w4[t];
+            const float wgt = wy * wx;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) {
+              if (PLAIN) accp[j][q][e] += wgt * xr[cq][e];
+              acca[j][q][e] += wgt * xa[cq][e];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int64_t o = (((int64_t)b * OH + 2 * by + j) * OW + 2 * bx + q) * C + c;
+        if (PLAIN) Vec16<T>::store(out_plain + o, accp[j][q]);
+        Vec16<T>::store(out_act + o, acca[j][q]);
+      }
+  }
+}
+
 // Tiled variant for the fused GroupNorm+SiLU case: the per-output kernel above evaluates the
 // activation once per TAP (16x per input element when upsampling, 4x when downsampling) and is
 // VALU-bound there.  Here a workgroup stages an input tile with its halo ONCE - raw and activated,
@@ -310,10 +404,10 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
   FDBM_CHECK(up || (H % 2 == 0 && W % 2 == 0), "fdbm_resample2x: downsampling needs even H, W (got %d x %d)", H, W);
   hipStream_t st = (hipStream_t)stream;
   // fused GroupNorm+SiLU on maps that tile: the LDS-staged kernel (one activation per input element)
-  // ... up to 64 x 64 pixels.  Above that the plain kernel - one output vector per thread, the activation recomputed
-  // per tap - is faster at every batch size once it runs on enough workgroups (measured: 48.6 -> 49.0 x real time
-  // at batch 1, 129.8 -> 134.2 at batch 64): the tiled kernel's 16-channel slices read 32 bytes of every 256-byte
-  // pixel per workgroup and its 18 x 18 staging pass keeps 60 % of the threads busy.
+  // ... up to 64 x 64 pixels.  Above that the register kernels (2 x 2 outputs per thread, or one output per thread where
+  // that leaves too few workgroups) are faster at every batch size (measured against the tiled kernel: 48.6 -> 49.0 x
+  // real time at batch 1, 129.8 -> 134.2 at batch 64): the tiled kernel's 16-channel slices read 32 bytes of every
+  // 256-byte pixel per workgroup and its 18 x 18 staging pass keeps 60 % of the threads busy.
   static const char* tmax = getenv("FDBM_RESAMPLE_TILE_MAXHW");       // experiments
   const int64_t tile_max_hw = tmax ? atoll(tmax) : 4096;
   if (out_act && C % 16 == 0 && (int64_t)H * W <= tile_max_hw && (up ? (H % 8 == 0 && W % 8 == 0) : (H % 16 == 0 && W % 16 == 0))) {
@@ -353,6 +447,32 @@ extern "C" int fdbm_resample2x_units(void* out_plain, void* out_act, const void*
 #undef RT
   }
   const int OH = up ? 2 * H : H / 2, OW = up ? 2 * W : W / 2;
+  // fused GroupNorm+SiLU on the large maps: a 2 x 2 output block per thread (shared activations)
+  static const char* qenv = getenv("FDBM_RESAMPLE_QUAD");              // experiments: 0 = the per-output kernel
+  // (where it still fills the chip: with fewer than 512 workgroups - the 128 x 128 x 128 level at batch 1 - the
+  //  per-output kernel's four times as many threads win, 9 us against 16)
+  const int64_t totalq = (int64_t)(OH / 2) * (OW / 2) * (C / vw);
+  if (out_act && !(qenv && qenv[0] == '0') && totalq * B >= 131072 && (up || (H % 4 == 0 && W % 4 == 0))) {
+    int chunks = (int)((totalq + 255) / 256);
+    if (chunks > 4096) chunks = 4096;
+    if (chunks < 1) chunks = 1;
+    dim3 grid(chunks, B);
+    const size_t smem = 2 * (size_t)C * sizeof(float);
+#define RQ(TT, U, P) resample2x_quad_kernel<TT, U, P><<<grid, 256, smem, st>>>((TT*)out_plain, (TT*)out_act, (const TT*)in, stats, nsplit, inv_count, eps, gamma, beta, H, W, C, G, chunks, stat_units)
+#define RQ_DISPATCH(TT)                                                         \
+  do {                                                                          \
+    if (up) { if (out_plain) RQ(TT, true, true); else RQ(TT, true, false); }    \
+    else    { if (out_plain) RQ(TT, false, true); else RQ(TT, false, false); }  \
+  } while (0)
+    if (dtype == FDBM_BF16) RQ_DISPATCH(bf16_t);
+    else if (dtype == FDBM_F16) RQ_DISPATCH(f16_t);
+    else if (dtype == FDBM_F32) RQ_DISPATCH(float);
+    else FDBM_CHECK(false, "fdbm_resample2x: bad dtype %d", dtype);
+#undef RQ_DISPATCH
+#undef RQ
+    FDBM_LAUNCH_CHECK("fdbm_resample2x(quad)");
+    return 0;
+  }
   const int64_t total = (int64_t)OH * OW * (C / vw);
   // one output vector per thread up to 2048 workgroups (4 per thread left a 1 MB pyramid level on 16 CUs: 13 us of latency)
   int chunks = (int)((total + 255) / 256);

@@ -154,8 +154,9 @@ def test_groupnorm(dtype, tol, C0, C1, G):
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 4e-2)])
-@pytest.mark.parametrize("shape", [(2, 32, 8, 12, 8), (2, 48, 32, 48, 12), (1, 128, 16, 32, 32)],
-                         ids=["per_output", "tiled_c48", "tiled_c128"])        # tiled: LDS-staged kernel (maps that tile by 16)
+@pytest.mark.parametrize("shape", [(2, 32, 8, 12, 8), (2, 48, 32, 48, 12), (1, 128, 16, 32, 32), (2, 128, 256, 256, 32), (1, 64, 66, 98, 16)],
+                         ids=["per_output", "tiled_c48", "tiled_c128", "quad", "large_not_by_4"])
+# tiled: LDS-staged kernel (maps that tile by 16); quad: 2 x 2 outputs per thread (large maps; down: H, W multiples of 4)
 @pytest.mark.parametrize("up", [False, True])
 def test_resample2x(dtype, tol, up, shape):
     B, C, H, W, G = shape

@@ -1,7 +1,7 @@
 """Per-kernel-family averages of rocprofv3 --pmc SQ counters (one directory per pass) -> table.
    python tools/pmc_sq_summarize.py DIR [DIR ...]"""
 import csv, glob, sys, collections, re
-FAMS = ("conv_ring_kernel", "conv_head_kernel", "conv_patch_kernel", "conv_tap_kernel", "resample2x_tile_kernel", "resample2x_kernel", "attention_mfma256_kernel",
+FAMS = ("conv_ring_kernel", "conv_head_kernel", "conv_patch_kernel", "conv_tap_kernel", "resample2x_tile_kernel", "resample2x_quad_kernel", "resample2x_kernel", "attention_mfma256_kernel",
         "conv_stem_mfma_kernel", "dense_rows_kernel")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for d in sys.argv[1:]:

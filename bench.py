@@ -304,10 +304,13 @@ def main():
     n_clips_step = args.clips if args.clips else world * args.batch
     audio_s = args.steps * n_clips_step * CLIP_SECONDS
     rtf = audio_s / elapsed
+    if world > 1:
+        # every rank leaves the process group HERE, together: rank 0's roofline measurements below are single-GPU work and
+        # would otherwise tear the communicator down minutes after its peers have exited
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     if rank != 0:
-        if world > 1:
-            import torch.distributed as dist
-            dist.destroy_process_group()
         return
 
     F, T = 257, 256
@@ -427,9 +430,6 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         result["cpu_baseline"] = cpu_baseline(args.cpu_forwards, args.N)
     print(json.dumps(result))
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

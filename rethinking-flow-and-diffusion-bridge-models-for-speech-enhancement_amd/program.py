@@ -527,11 +527,14 @@ class Program:
         # beside pack / stem / the first level and are joined where their first consumer is)
         self.fork()
         self.lane = 1
+        self.op_temb = len(self.ops)
         self.emit(hip.OP_TEMB, [self.temb_act.data_ptr(), self.t_in.data_ptr(), net.fourier_w.data_ptr(),
                                 net.lin1_w.data_ptr(), net.lin1_b.data_ptr(), net.lin2_w.data_ptr(),
                                 net.lin2_b.data_ptr(), temb_scratch.data_ptr(), B, nf])
+        self.op_dense = len(self.ops)
         self.emit(hip.OP_DENSE, [self.dense_out.data_ptr(), self.temb_act.data_ptr(), net.dense_w.data_ptr(),
                                  net.dense_b.data_ptr(), B, net.dense_rows, 4 * nf])
+        assert self.op_dense == self.op_temb + 1
         ev_dense = self.mark()
         self.lane = 0
         self.macs += 2 * nf * 4 * nf + 4 * nf * 4 * nf + net.dense_rows * 4 * nf
@@ -695,6 +698,35 @@ class Program:
     def run(self):
         """Enqueue the whole forward on the current stream (reads x_in/y_in/t_in, writes s_out)."""
         hip.call("fdbm_run_program", self.op_array, self.n_ops)
+
+    def run_body(self):
+        """The forward WITHOUT its time-embedding chain (OP_TEMB, OP_DENSE): for callers that have put the Dense_0 rows of
+        this evaluation's t into `dense_out` themselves (the sampler graphs: the rows of all N steps depend on the time
+        grid only and are computed once per sampler call, in front of the step loop: `dense_table`)."""
+        self.run_range(0, self.op_temb)
+        self.run_range(self.op_dense + 1, self.n_ops)
+
+    def dense_table(self, log_t, bufs=None):
+        """log_t: f32 device tensor of M model times (log t) -> [M, dense_rows] f32: act(temb) through every res-block's
+        Dense_0 (layerspp.py:261-263), by the same two kernels OP_TEMB / OP_DENSE run (rows are independent of the batch
+        they are computed in: bit-identical to the per-forward evaluation).  bufs = dense_table_buffers(M): no allocation
+        and no synchronisation (the call can be captured into a graph)."""
+        net = self.net
+        nf = net.spec.nf
+        M = log_t.numel()
+        assert log_t.is_contiguous() and log_t.dtype == torch.float32
+        act, scratch, out = bufs if bufs is not None else self.dense_table_buffers(M)
+        hip.call("fdbm_temb", hip.ptr(act), hip.ptr(log_t), hip.ptr(net.fourier_w), hip.ptr(net.lin1_w), hip.ptr(net.lin1_b),
+                 hip.ptr(net.lin2_w), hip.ptr(net.lin2_b), hip.ptr(scratch), M, nf)
+        hip.call("fdbm_dense_rows", hip.ptr(out), hip.ptr(act), hip.ptr(net.dense_w), hip.ptr(net.dense_b), M, net.dense_rows, 4 * nf)
+        if bufs is None:
+            torch.cuda.current_stream().synchronize()          # act / scratch may go now
+        return out
+
+    def dense_table_buffers(self, M):
+        nf = self.net.spec.nf
+        act = torch.empty(M * 4 * nf, dtype=torch.float32, device=self.dev)
+        return act, torch.empty_like(act), torch.empty(M, self.net.dense_rows, dtype=torch.float32, device=self.dev)
 
     def run_range(self, lo, hi):
         sub = ctypes.cast(ctypes.byref(self.op_array, lo * ctypes.sizeof(hip.Op)), ctypes.POINTER(hip.Op))

@@ -143,6 +143,34 @@ def test_sampler_batched_and_graph_equals_eager(golden):
     assert (a.cpu() - T(g["mini64_sb_bb_ode_ei_N3"])).abs().max() < 4e-3
 
 
+def test_time_embedding_rows_hoisted_out_of_the_step_loop(golden):
+    """Program.dense_table (the sampler graphs' batched time-embedding pass) gives, bit for bit, the rows a forward
+    computes for itself, and run_body() on those rows equals run()."""
+    g = golden("backbone_mini64")
+    x, y, t = T(g["x"]).to(DEV), T(g["y"]).to(DEV), T(g["t"]).to(DEV)
+    m = net("mini64")
+    B, _, F, Tn = x.shape
+    prog = m.program(B, F, Tn)
+    ref = m(x, y, t).clone()                                  # full forward: leaves its Dense_0 rows in prog.dense_out
+    R = m.dense_rows
+    dense_out = prog.dense_out.view(torch.float32)            # (pool buffers are raw bytes)
+    rows_fwd = dense_out[: B * R].clone().reshape(B, R)
+    ts = torch.cat([t.float() * 0.5, t.float(), t.float() * 0.25]).cpu()      # 3 "steps" of B times, the forward's in the middle
+    tab = prog.dense_table(torch.log(ts).to(DEV).contiguous())       # log t on the host, like HipNCSNpp.forward
+    assert tab.shape == (3 * B, R)
+    assert torch.equal(tab[B:2 * B], rows_fwd)
+    assert not torch.equal(tab[:B], rows_fwd)
+    # another step's rows in place, then the body alone: differs; the right rows: the full forward again, bit for bit
+    prog.x_in.copy_(x); prog.y_in.copy_(y)
+    dense_out[: B * R].copy_(tab[:B].reshape(-1))
+    prog.run_body()
+    assert not torch.equal(torch.view_as_real(prog.s_out), torch.view_as_real(ref))
+    dense_out[: B * R].copy_(tab[B:2 * B].reshape(-1))
+    prog.run_body()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.view_as_real(prog.s_out), torch.view_as_real(ref))
+
+
 def test_batch_rows_are_independent():
     """Samples of a batch never mix (GroupNorm and attention are per sample): evaluating [a, b] gives, row by
     row, what evaluating [a] and [b] gives - up to rounding, because the kernel / tile choice depends on the

@@ -42,6 +42,17 @@ int fdbm_bridge_update(void* out, const void* a, const void* b, const void* c,
                        const float* wa, const float* wb, const float* wc,
                        int B, int64_t n_complex, void* stream);
 
+/* Step boundary of the ei samplers inside a replayed graph (fdbm/bridge.py:73-85, :96-111): in ONE launch, elementwise
+ * over [B][F][T]:  s = out-conv(pyramid) (ncsnpp_v2.py:391-399; rows f >= Fn are 0);  x = (wa*x + wb*s) + wc*third
+ * (fdbm_bridge_update's arithmetic);  packed[b][f < Fn][t] = (x.re, x.im, y.re, y.im) = the next evaluation's network
+ * input (ncsnpp_v2.py:246-251);  zero_bytes at zero_ptr set to 0 (the statistics arena);  dense_n floats copied (the next
+ * evaluation's time-embedding rows).  pyramid NULL: no update (the boundary in front of the first evaluation);
+ * packed NULL: no packing (behind the last one).  zero_ptr / dense_* may be NULL / 0. */
+int fdbm_step_boundary(void* x, const void* y, const void* third, const float* pyramid, const float* out_w,
+                       const float* out_b, const float* wa, const float* wb, const float* wc, float* packed,
+                       void* zero_ptr, int64_t zero_bytes, float* dense_dst, const float* dense_src,
+                       int64_t dense_n, int B, int F, int Fn, int T, void* stream);
+
 /* Euler-Maruyama predictor move (fdbm/util/predictors.py:44-51 + ProbabilityPathSB.sde,
  * fdbm/bridge.py:294-306): drift = (wx*x + ws*s) + wy*y; x_mean = x + drift*dt;
  * x_new = x_mean + (gd*sqrt(-dt))*z.  Weights are [B] device floats; dt a host scalar. */

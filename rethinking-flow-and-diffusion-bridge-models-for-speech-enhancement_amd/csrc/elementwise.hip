@@ -70,6 +70,79 @@ extern "C" int fdbm_bridge_update(void* out, const void* a, const void* b, const
 }
 
 // ---------------------------------------------------------------------------------
+// step boundary of the exponential-integrator samplers inside a replayed graph: what sits between two backbone
+// evaluations - unpack_output (pyramid -> score, ncsnpp_v2.py:391-399), the state update (fdbm_bridge_update), the
+// next evaluation's pack_input, the zeroing of its statistics arena and the copy of its time-embedding rows - as ONE
+// launch instead of five (each 4-5 us of launch floor at batch 1).  Elementwise in (b, f, t); the arithmetic of the
+// score and of the update is the two kernels' own, expression for expression (bit-identical results).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) step_boundary_kernel(
+    f32x2* __restrict__ x, const f32x2* __restrict__ y, const f32x2* __restrict__ third,
+    const f32x4* __restrict__ pyr, const float* __restrict__ ow, const float* __restrict__ ob,
+    const float* __restrict__ wa, const float* __restrict__ wb, const float* __restrict__ wc,
+    f32x4* __restrict__ inp, uint4* __restrict__ zero16, int64_t nzero16,
+    float* __restrict__ dense_dst, const float* __restrict__ dense_src, int64_t ndense,
+    int F, int Fn, int T, int64_t total) {
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (int64_t)gridDim.x * blockDim.x;
+  float w00 = 0, w01 = 0, w02 = 0, w03 = 0, w10 = 0, w11 = 0, w12 = 0, w13 = 0, b0 = 0, b1 = 0;
+  if (pyr) {
+    w00 = ow[0]; w01 = ow[1]; w02 = ow[2]; w03 = ow[3];
+    w10 = ow[4]; w11 = ow[5]; w12 = ow[6]; w13 = ow[7];
+    b0 = ob[0]; b1 = ob[1];
+  }
+  for (int64_t i = gtid; i < total; i += gstride) {
+    const int t = (int)(i % T);
+    const int64_t r = i / T;
+    const int f = (int)(r % F);
+    const int64_t b = r / F;
+    f32x2 xv = x[i];
+    const f32x2 yv = y[i];
+    if (pyr) {
+      f32x2 o = {0.f, 0.f};
+      if (f < Fn) {
+        const f32x4 p = pyr[(b * Fn + f) * T + t];
+        o[0] = b0 + (((w00 * p[0] + w01 * p[1]) + w02 * p[2]) + w03 * p[3]);
+        o[1] = b1 + (((w10 * p[0] + w11 * p[1]) + w12 * p[2]) + w13 * p[3]);
+      }
+      const float fa = wa[b], fb = wb[b], fc = wc[b];
+      const f32x2 cv = third[i];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        float sv = __fadd_rn(__fmul_rn(fa, xv[k]), __fmul_rn(fb, o[k]));
+        sv = __fadd_rn(sv, __fmul_rn(fc, cv[k]));
+        xv[k] = sv;
+      }
+      x[i] = xv;
+    }
+    if (inp && f < Fn) {
+      f32x4 o4 = {xv[0], xv[1], yv[0], yv[1]};
+      inp[(b * Fn + f) * T + t] = o4;
+    }
+  }
+  for (int64_t i = gtid; i < nzero16; i += gstride) zero16[i] = uint4{0u, 0u, 0u, 0u};
+  for (int64_t i = gtid; i < ndense; i += gstride) dense_dst[i] = dense_src[i];
+}
+
+extern "C" int fdbm_step_boundary(void* x, const void* y, const void* third, const float* pyramid, const float* out_w,
+                                  const float* out_b, const float* wa, const float* wb, const float* wc, float* packed,
+                                  void* zero_ptr, int64_t zero_bytes, float* dense_dst, const float* dense_src,
+                                  int64_t dense_n, int B, int F, int Fn, int T, void* stream) {
+  FDBM_CHECK(x && y, "fdbm_step_boundary: null state");
+  FDBM_CHECK(!pyramid || (third && out_w && out_b && wa && wb && wc), "fdbm_step_boundary: the update needs third, out_w, out_b, wa, wb, wc");
+  FDBM_CHECK(B > 0 && Fn > 0 && Fn <= F && T > 0, "fdbm_step_boundary: bad shape");
+  FDBM_CHECK(zero_bytes >= 0 && zero_bytes % 16 == 0 && (((uintptr_t)zero_ptr) & 15) == 0, "fdbm_step_boundary: the zeroed range must be 16-byte aligned and sized");
+  FDBM_CHECK(dense_n >= 0 && (dense_n == 0 || (dense_dst && dense_src)), "fdbm_step_boundary: bad time-embedding rows");
+  const int64_t total = (int64_t)B * F * T;
+  int g = (int)((total + 255) / 256);
+  if (g > 4096) g = 4096;
+  step_boundary_kernel<<<g, 256, 0, (hipStream_t)stream>>>(
+      (f32x2*)x, (const f32x2*)y, (const f32x2*)third, (const f32x4*)pyramid, out_w, out_b, wa, wb, wc, (f32x4*)packed,
+      (uint4*)zero_ptr, zero_ptr ? zero_bytes / 16 : 0, dense_dst, dense_src, dense_n, F, Fn, T, total);
+  FDBM_LAUNCH_CHECK("fdbm_step_boundary");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // predictor / corrector moves
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pc_predictor_kernel(

@@ -4,10 +4,13 @@
 The reference's inner loop (fdbm/bridge.py:73-85, :96-111) launches ~1.1k framework ops
 plus ~45 tiny scalar kernels per step from Python.  Here one replay of one graph runs
 all N steps: first the time-embedding rows of all N steps (the Dense_0 projections of every res-block: a function of
-the time grid only, hoisted out of the step loop), then per step a copy of the step's rows, the recorded backbone program without its
-time-embedding chain (program.py, run_body) and ONE fdbm_bridge_update kernel that updates the state in place.
+the time grid only, hoisted out of the step loop), then per step the recorded backbone program between its input packing
+and its output conv (program.py, run_core) and ONE fdbm_step_boundary launch: score from the output pyramid, the state
+update, the next evaluation's packed input, its zeroed statistics arena and its time-embedding rows.
 The per-step weights come from the host table (bridge.ei_weight_table) uploaded once.
 """
+import os
+
 import torch
 
 from . import hip
@@ -37,20 +40,41 @@ class SamplerGraph:
 
     def _steps(self):
         prog = self.prog
-        n = prog.x_in[0].numel()
-        B = prog.B
+        B, F, T = prog.B, prog.F, prog.T
         R = self.net.dense_rows
+        p = hip.ptr
         # the time-embedding chain (2 + 1 launches per evaluation in the reference's loop) is a function of the time grid
         # only: hoisted out of the step loop - evaluated HERE for all N steps, once per sampler call, inside the graph
         self.dense_tab = prog.dense_table(self.t_tab, self.dense_bufs)
+        ba = prog.boundary_args()
+
+        def boundary(i_done, i_next):
+            """Between evaluation i_done (None: none yet) and evaluation i_next (None: none left): score -> state update ->
+            next network input, arena zeroing and time-embedding rows, ONE launch (fdbm_step_boundary)."""
+            upd = i_done is not None
+            nxt = i_next is not None
+            w = self.table[i_done] if upd else None
+            third = (prog.y_in if self.kind == "ode" else self.z[i_done]) if upd else None
+            hip.call("fdbm_step_boundary", p(prog.x_in), p(prog.y_in), p(third),
+                     ba["pyramid"] if upd else 0, ba["out_w"] if upd else 0, ba["out_b"] if upd else 0,
+                     p(w[0]) if upd else 0, p(w[1]) if upd else 0, p(w[2]) if upd else 0,
+                     ba["packed"] if nxt else 0, ba["arena"] if nxt else 0, ba["arena_bytes"] if nxt else 0,
+                     p(prog.dense_out) if nxt else 0, p(self.dense_tab[i_next * B]) if nxt else 0, B * R if nxt else 0,
+                     B, F, ba["Fn"], T)
+
+        if os.environ.get("FDBM_STEP_BOUNDARY", "1") == "0":          # A/B (tools/step_ab.py): the five separate launches per step
+            n = prog.x_in[0].numel()
+            for i in range(self.N):
+                hip.call("fdbm_copy_f32", p(prog.dense_out), p(self.dense_tab[i * B]), B * R)
+                prog.run_body()
+                third = prog.y_in if self.kind == "ode" else self.z[i]
+                w = self.table[i]
+                hip.call("fdbm_bridge_update", p(prog.x_in), p(prog.x_in), p(prog.s_out), p(third), p(w[0]), p(w[1]), p(w[2]), B, n)
+            return
+        boundary(None, 0)
         for i in range(self.N):
-            # the step copies its rows into place (a library kernel inside the graph) and runs the rest of the forward
-            hip.call("fdbm_copy_f32", hip.ptr(prog.dense_out), hip.ptr(self.dense_tab[i * B]), B * R)
-            prog.run_body()
-            third = prog.y_in if self.kind == "ode" else self.z[i]
-            w = self.table[i]
-            hip.call("fdbm_bridge_update", hip.ptr(prog.x_in), hip.ptr(prog.x_in), hip.ptr(prog.s_out),
-                     hip.ptr(third), hip.ptr(w[0]), hip.ptr(w[1]), hip.ptr(w[2]), B, n)
+            prog.run_core()
+            boundary(i, i + 1 if i + 1 < self.N else None)
 
     def capture(self):
         self.dense_bufs = self.prog.dense_table_buffers(self.t_tab.numel())

@@ -56,6 +56,7 @@ OP_CONV, OP_GN_STATS, OP_GN_FINALIZE, OP_GN_APPLY, OP_RESAMPLE, OP_COMBINE, OP_A
 # name -> (argtypes without the trailing stream)
 _SIGS = {
     "fdbm_bridge_update": [c_void_p] * 7 + [c_int, c_i64],
+    "fdbm_step_boundary": [c_void_p] * 11 + [c_i64, c_void_p, c_void_p, c_i64] + [c_int] * 4,
     "fdbm_pc_predictor": [c_void_p] * 10 + [c_float, c_int, c_i64],
     "fdbm_pc_corrector": [c_void_p] * 11 + [c_int, c_i64],
     "fdbm_langevin_step": [c_void_p] * 10 + [c_float, c_int, c_i64],

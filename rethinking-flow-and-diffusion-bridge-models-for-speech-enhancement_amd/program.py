@@ -652,6 +652,7 @@ class Program:
         assert not hs and mi[0] == len(mods)
         self.free_act(h)
         ow = net.w[-1]
+        self.op_unpack = len(self.ops)
         self.emit(hip.OP_UNPACK, [self.s_out.data_ptr(), pyramid.ptr, ow["w"].data_ptr(), ow["b"].data_ptr(),
                                   B, F, Fn, T])
         self.macs += Fn * T * IN_CH * OUT_CH
@@ -705,6 +706,21 @@ class Program:
         grid only and are computed once per sampler call, in front of the step loop: `dense_table`)."""
         self.run_range(0, self.op_temb)
         self.run_range(self.op_dense + 1, self.n_ops)
+
+    def run_core(self):
+        """The forward between two step boundaries of a sampler graph: everything but the arena memset, the
+        time-embedding chain, pack_input and unpack_output - those five launches per step are ONE
+        fdbm_step_boundary launch there (engine.SamplerGraph)."""
+        assert self.op_memset == 0 and self.op_unpack == self.n_ops - 1
+        self.run_range(1, self.op_temb)
+        self.run_range(self.op_dense + 1, self.op_pack)
+        self.run_range(self.op_pack + 1, self.op_unpack)
+
+    def boundary_args(self):
+        """Pointers fdbm_step_boundary needs from the recorded program: (packed input, arena, arena bytes,
+        final pyramid, output conv weight, bias, Fn)."""
+        pk, un, ms = self.ops[self.op_pack][1], self.ops[self.op_unpack][1], self.ops[self.op_memset][1]
+        return dict(packed=pk[0], arena=ms[0], arena_bytes=(ms[1] + 15) // 16 * 16, pyramid=un[1], out_w=un[2], out_b=un[3], Fn=un[6])
 
     def dense_table(self, log_t, bufs=None):
         """log_t: f32 device tensor of M model times (log t) -> [M, dense_rows] f32: act(temb) through every res-block's

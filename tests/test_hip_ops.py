@@ -66,6 +66,49 @@ def test_bridge_update_bit_exact():
     assert torch.equal(torch.view_as_real(a), torch.view_as_real(ref))
 
 
+def test_step_boundary_equals_the_separate_launches():
+    """fdbm_step_boundary == unpack_output -> bridge_update -> pack_input (+ memset, + copy), bit for bit, and its two
+    partial forms (no update in front of the first evaluation, no packing behind the last)."""
+    for B, F, Tn in ((2, 257, 64), (1, 257, 256), (3, 256, 16)):
+        Fn = 256
+        x, y, z = (crnd(B, 1, F, Tn, seed=s).to(DEV) for s in (1, 2, 3))
+        pyr = rnd(B, Fn, Tn, 4, seed=4).to(DEV).contiguous()
+        ow, ob = rnd(2, 4, seed=5).to(DEV).contiguous(), rnd(2, seed=6).to(DEV)
+        wa, wb, wc = (torch.tensor(v[:B], device=DEV) for v in ([1794.7899, 0.7, -2.5], [0.0333, 1.3, 0.25], [-1793.82, 0.1, 3.0]))
+        # the separate launches
+        s_out = torch.empty_like(x)
+        hip.call("fdbm_unpack_output", hip.ptr(s_out), hip.ptr(pyr), hip.ptr(ow), hip.ptr(ob), B, F, Fn, Tn)
+        x_ref = x.clone()
+        hip.call("fdbm_bridge_update", hip.ptr(x_ref), hip.ptr(x_ref), hip.ptr(s_out), hip.ptr(z), hip.ptr(wa), hip.ptr(wb), hip.ptr(wc), B, F * Tn)
+        inp_ref = torch.empty(B, Fn, Tn, 4, device=DEV)
+        hip.call("fdbm_pack_input", hip.ptr(inp_ref), hip.ptr(x_ref), hip.ptr(y), B, F, Fn, Tn)
+        # one launch
+        x1 = x.clone()
+        inp = torch.full((B, Fn, Tn, 4), float("nan"), device=DEV)
+        arena = torch.full((1024 + 8,), 7.0, dtype=torch.float64, device=DEV)
+        dsrc, ddst = rnd(B * 37, seed=7).to(DEV), torch.zeros(B * 37 + 3, device=DEV)
+        hip.call("fdbm_step_boundary", hip.ptr(x1), hip.ptr(y), hip.ptr(z), hip.ptr(pyr), hip.ptr(ow), hip.ptr(ob), hip.ptr(wa), hip.ptr(wb),
+                 hip.ptr(wc), hip.ptr(inp), hip.ptr(arena), 1024 * 8, hip.ptr(ddst), hip.ptr(dsrc), B * 37, B, F, Fn, Tn)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.view_as_real(x1), torch.view_as_real(x_ref))
+        assert torch.equal(inp, inp_ref)
+        assert not arena[:1024].any() and (arena[1024:] == 7.0).all()
+        assert torch.equal(ddst[:B * 37], dsrc) and not ddst[B * 37:].any()
+        # in front of the first evaluation: pack only
+        x2 = x.clone()
+        inp2 = torch.empty_like(inp)
+        hip.call("fdbm_step_boundary", hip.ptr(x2), hip.ptr(y), 0, 0, 0, 0, 0, 0, 0, hip.ptr(inp2), 0, 0, 0, 0, 0, B, F, Fn, Tn)
+        hip.call("fdbm_pack_input", hip.ptr(inp_ref), hip.ptr(x), hip.ptr(y), B, F, Fn, Tn)
+        assert torch.equal(torch.view_as_real(x2), torch.view_as_real(x)) and torch.equal(inp2, inp_ref)
+        # behind the last one: update only
+        x3 = x.clone()
+        hip.call("fdbm_step_boundary", hip.ptr(x3), hip.ptr(y), hip.ptr(z), hip.ptr(pyr), hip.ptr(ow), hip.ptr(ob), hip.ptr(wa), hip.ptr(wb),
+                 hip.ptr(wc), 0, 0, 0, 0, 0, 0, B, F, Fn, Tn)
+        assert torch.equal(torch.view_as_real(x3), torch.view_as_real(x_ref))
+    with pytest.raises(RuntimeError):          # an update without its operands
+        hip.call("fdbm_step_boundary", hip.ptr(x3), hip.ptr(y), 0, hip.ptr(pyr), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, F, Fn, Tn)
+
+
 def test_pc_moves():
     B = 2
     x, s, y, z = (crnd(B, 1, 257, 16, seed=i) for i in range(4))

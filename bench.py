@@ -64,12 +64,12 @@ def synth_clips(B, seed, device):
 class HotPath:
     """waveforms in HBM -> enhanced waveforms in HBM, everything through libfdbm_hip.so."""
 
-    def __init__(self, device, dtype, n_steps, batch, backbone="ncsnpp_v2", bridge="sb", schedule="bb", sampler="ode_ei"):
+    def __init__(self, device, dtype, n_steps, batch, backbone="ncsnpp_v2", bridge="sb", schedule="bb", sampler="ode_ei", split=False):
         import fdbm_amd
         from fdbm_amd.frontend import SpecFrontend, pad_mode_for
         self.dev = device
         self.B = batch
-        self.net = fdbm_amd.BackboneRegistry.get_by_name(backbone)(dtype=dtype, device=device)
+        self.net = fdbm_amd.BackboneRegistry.get_by_name(backbone)(dtype=dtype, device=device, **(dict(split=True) if split else {}))
         self.fe = SpecFrontend(n_fft=512, hop_length=256, window="sqrthann", device=device)   # config.yaml:35-38
         self.bridge = fdbm_amd.Bridge(bridge, N=n_steps, sampler_type=sampler, noise_schedule=schedule)
         self.pad_mode = pad_mode_for(backbone)
@@ -205,7 +205,10 @@ def main():
                     help="configs[3]: a list of this many synthetic clips, strided over the ranks, enhanced in batches of "
                          "--batch; a step = the whole list once (strong scaling)")
     ap.add_argument("--N", type=int, default=30, help="sampler steps")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "f32s"],
+                    help="bf16 / f16: 16-bit storage, f32 accumulation (throughput modes); f32: f32 storage, exact f32 MFMA; "
+                         "f32s: f32 storage, split-precision matrix products (three f16 MFMAs over 22-bit (hi, lo) operand pairs) - "
+                         "the parity mode that runs on the 16-bit matrix pipe")
     ap.add_argument("--sampler", default="ode_ei", choices=["ode_ei", "sde_ei", "pc"],
                     help="ode_ei = configs[1..3]; sde_ei / pc with --batch 16 --N 100 --dtype f16 = configs[4]")
     ap.add_argument("--backbone", default="ncsnpp_v2")
@@ -239,11 +242,12 @@ def main():
         assert comm_world == args.gpus, (comm_world, args.gpus)
     torch.cuda.set_device(local_rank)
     dev = torch.device(f"cuda:{local_rank}")
-    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32s": torch.float32}[args.dtype]
+    split = args.dtype == "f32s"
     evals_per_step = 2 * args.N if args.sampler == "pc" else args.N        # pc: predictor + 1 corrector evaluation
 
     from fdbm_amd import dist as fdist
-    hp = HotPath(dev, dtype, args.N, args.batch, backbone=args.backbone, sampler=args.sampler)
+    hp = HotPath(dev, dtype, args.N, args.batch, backbone=args.backbone, sampler=args.sampler, split=split)
     if args.clips:
         # configs[3]: the list is sharded by index (rank r takes clips r, r + W, ...: fdbm_amd.dist.shard_indices), every
         # rank walks its shard in batches of --batch (a ragged last batch is padded with its first clip and trimmed)

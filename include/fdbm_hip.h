@@ -246,6 +246,18 @@ typedef struct {
    * order of fdbm_resample2x - the progressive-output pyramid (ncsnpp_v2.py:379-383) without its own
    * upsampling launch.  H and W even. */
   const float* res_up2x;
+  /* optional SPLIT-PRECISION matrix mode for FDBM_F32 tensors (mma_mode 1; 0 = exact f32 MFMA, the default):
+   * f32 storage, f32 GroupNorm / SiLU / epilogue exactly as in the f32 mode, but the products run on the 16-bit
+   * matrix pipe with both operands carried as two IEEE halves, x ~ hi + lo (22 significant bits):
+   *   a.w ~ a_hi.w_hi + a_hi.w_lo + a_lo.w_hi   (three v_mfma_f32_16x16x32_f16 per 32 input channels, f32 sums;
+   *   the dropped a_lo.w_lo term is 2^-22 of the product) - 5.3x less matrix-pipe time than v_mfma_f32_16x16x4_f32.
+   * Activations are split where they are staged (hi = half(16 a), lo = half(16 a - hi), |16 a| clamped to 65504).
+   * `w` / `w_frag` then hold PRE-SPLIT weights: per k-step and output channel a 128-byte row of 32 input channels as
+   * [32 halves hi | 32 halves lo] of  s_w * w  with s_w a power of two chosen by the packer (max |s_w w| < 2^15);
+   * acc_scale = 1 / (16 s_w) is applied to the f32 sums before the bias.  Halo-patch and wave-per-tap kernels only
+   * (plan kinds 1 and 2); fdbm_conv_igemm fails for a kind-0 shape with mma_mode 1. */
+  int32_t mma_mode;
+  float acc_scale;
 } fdbm_conv_args;
 
 int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream);

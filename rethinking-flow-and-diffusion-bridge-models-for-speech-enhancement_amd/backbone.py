@@ -41,7 +41,7 @@ class HipNCSNpp:
         return parser
 
     def __init__(self, nf=128, ch_mult=(1, 1, 2, 2, 2, 2, 2), num_res_blocks=2, attn_resolutions=(16,),
-                 dtype=torch.bfloat16, device=None, state=None, seed=0, fused=None, **unused_kwargs):
+                 dtype=torch.bfloat16, device=None, state=None, seed=0, fused=None, split=False, **unused_kwargs):
         if not torch.cuda.is_available():
             raise RuntimeError("HipNCSNpp needs a HIP device (torch.cuda.is_available() is False); "
                                "there is no CPU fallback")
@@ -50,6 +50,12 @@ class HipNCSNpp:
                          attn_resolutions=attn_resolutions)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.dtype = dtype
+        # split-precision parity mode (dtype float32 only): f32 storage and f32 GroupNorm / SiLU / epilogues exactly as in
+        # the f32 mode, but the convolutions' products run on the 16-bit matrix pipe as three f16 MFMAs over (hi, lo)
+        # operand pairs (include/fdbm_hip.h, fdbm_conv_args.mma_mode): 22-bit operands, f32 sums.
+        self.split = bool(split)
+        if self.split and dtype != torch.float32:
+            raise ValueError("split=True is a mode of dtype=torch.float32 (f32 tensors, split-precision matrix products)")
         # fused mode (default in both dtypes): GroupNorm statistics come from the producing kernels' epilogues as fp64
         # unit sums, GroupNorm + SiLU are applied inside the consuming conv / resample, Combine in the epilogue.
         # With fp64 statistics it is run-to-run reproducible and, in f32, slightly closer to the reference than
@@ -161,6 +167,7 @@ class HipNCSNpp:
         self._programs.clear()
         self._graphs.clear()
         self._frag = {}
+        self._split = {}
         return self
 
     def _concat_split(self, mod):
@@ -182,6 +189,17 @@ class HipNCSNpp:
         if hit is None or hit[0] is not wpack:        # (the packed tensor is kept with its copy: an address alone can be reused)
             hit = self._frag[key] = (wpack, frag_major(wpack))
         return hit[1]
+
+    def split_weight(self, wpack):
+        """Pre-split copy of a packed f32 conv weight for fdbm_conv_args.mma_mode 1 -> (tensor, acc_scale): every
+        128-byte row of 32 channels becomes [32 halves hi | 32 halves lo] of s_w * w, s_w the power of two that puts
+        max |s_w w| in [2^13, 2^14); acc_scale = 1 / (16 s_w) undoes it (and the activations' factor 16) on the f32 sums."""
+        from .program import split_pack
+        key = wpack.data_ptr()
+        hit = self._split.get(key)
+        if hit is None or hit[0] is not wpack:
+            hit = self._split[key] = (wpack,) + split_pack(wpack)
+        return hit[1], hit[2]
 
     # ---- programs ------------------------------------------------------------------------
     MAX_PROGRAMS = 4      # shapes kept at once: a Program owns a full activation pool (linear in B), a graph per sampler

@@ -612,6 +612,8 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   FDBM_CHECK(a->dt_in == FDBM_F32 || a->dt_in == FDBM_BF16 || a->dt_in == FDBM_F16, "fdbm_conv_igemm: bad dt_in %d", a->dt_in);
   FDBM_CHECK(a->dt_out == FDBM_F32 || a->dt_out == a->dt_in, "fdbm_conv_igemm: bad dt_out %d", a->dt_out);
   FDBM_CHECK(!(a->dt_in == FDBM_F32 && a->dt_out != FDBM_F32), "fdbm_conv_igemm: f32 in / bf16 out is not built");
+  FDBM_CHECK(a->mma_mode == 0 || (a->mma_mode == 1 && a->dt_in == FDBM_F32 && a->dt_out == FDBM_F32 && a->acc_scale > 0.f),
+             "fdbm_conv_igemm: mma_mode %d needs f32 tensors and a positive acc_scale", a->mma_mode);
   FDBM_CHECK(a->Cout > 0 && a->Cout % 4 == 0, "fdbm_conv_igemm: Cout=%d must be a positive multiple of 4", a->Cout);
   FDBM_CHECK(a->CoutPad >= a->Cout && a->CoutPad % 128 == 0, "fdbm_conv_igemm: CoutPad=%d must be a multiple of 128 >= Cout", a->CoutPad);
   FDBM_CHECK(a->B > 0 && a->H > 0 && a->W > 0, "fdbm_conv_igemm: bad shape B=%d H=%d W=%d", a->B, a->H, a->W);
@@ -636,6 +638,8 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
   FDBM_CHECK(!a->res_up2x || (a->H % 2 == 0 && a->W % 2 == 0), "fdbm_conv_igemm: res_up2x needs even H, W (got %d x %d)", a->H, a->W);
   p.B = a->B; p.H = a->H; p.W = a->W; p.Cout = a->Cout; p.CoutPad = a->CoutPad;
   p.nk = nk;
+  p.mma_split = a->mma_mode == 1;
+  p.acc_scale = a->mma_mode == 1 ? a->acc_scale : 1.0f;
   int bm, bn, ks, kind, th;
   const int64_t M = (int64_t)a->B * a->H * a->W;
   fdbm_conv_plan_ex(a->B, a->H, a->W, a->Cout, nk, a->seg[0].taps, &kind, &th, &bm, &bn, &ks);
@@ -650,6 +654,8 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
       fdbm_conv_plan(M, a->Cout, nk, &bm, &bn, &ks);
     }
   }
+  FDBM_CHECK(!(p.mma_split && kind == 0), "fdbm_conv_igemm: the split-precision mode (mma_mode 1) is built for plan kinds 1 and 2 only "
+             "(this shape takes the tap-outer kernel: pass plain f32 weights with mma_mode 0)");
   if (kind != 0) bm = 16;          // a patch / tap tile always lies inside one image
   if (!a->workspace || a->workspace_bytes <= 0) ks = 1;
   while (ks > 1 && (int64_t)ks * M * a->Cout * 4 > a->workspace_bytes) --ks;

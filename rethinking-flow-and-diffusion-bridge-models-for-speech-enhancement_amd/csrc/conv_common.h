@@ -83,7 +83,29 @@ struct ConvParams {
   double* stat_out;  // fp64: the atomics' order then changes the sums by ~1e-16, not by fp32 last bits
   int stat_G;
   int stat_nsplit;   // stat_out is [B][stat_nsplit][stat_G][2]; a block adds into split blockIdx.x % nsplit
+  // split-precision matrix mode (fdbm_conv_args.mma_mode 1): f32 tensors, operands as IEEE-half (hi, lo) pairs
+  int mma_split;
+  float acc_scale;   // 1 / (SPLIT_ACT_SCALE * weight scale): applied to the f32 sums before the epilogue
 };
+
+// ---- split-precision operands ---------------------------------------------------------------------------
+// An f32 activation a is staged as hi = half(16 a), lo = half(16 a - hi): hi + lo carries 22 significant bits
+// of 16 a (the factor keeps lo a NORMAL half down to |a| ~ 8e-3; below that its absolute error is < 2e-9).
+// |16 a| is clamped to the largest half so that an outlier saturates instead of becoming an infinity.
+// LDS / weight rows of 128 bytes hold 32 channels as [32 halves hi | 32 halves lo]: the 16-byte chunk c < 4 is the
+// k-group c of v_mfma_f32_16x16x32_f16's operand (8 consecutive channels), chunk 4 + c the same k-group of lo.
+#define SPLIT_ACT_SCALE 16.0f
+__device__ __forceinline__ void split_f16x4(const f32x4& x, uint2& hi, uint2& lo) {
+  f16x4 h, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float s = __builtin_amdgcn_fmed3f(x[q] * SPLIT_ACT_SCALE, -65504.f, 65504.f);
+    h[q] = (f16_t)s;
+    l[q] = (f16_t)(s - (float)h[q]);
+  }
+  hi = *reinterpret_cast<uint2*>(&h);
+  lo = *reinterpret_cast<uint2*>(&l);
+}
 
 // sum over the 16 lanes of a DPP row (= the 16 pixels of an MFMA m-tile), every lane gets it:
 // quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror - four VALU adds.

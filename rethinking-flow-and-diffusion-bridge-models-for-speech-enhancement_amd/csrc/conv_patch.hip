@@ -20,7 +20,9 @@
 // path with the centre tap only.
 #include "conv_common.h"
 
-template <typename T, typename TO, int TH, int BN, bool GNP>
+// SPL (T = float only): split-precision matrix mode - patch and weight rows hold [32 halves hi | 32 halves lo]
+// (conv_common.h), every product is three f16 MFMAs: hi.hi + hi.lo + lo.hi.
+template <typename T, typename TO, int TH, int BN, bool GNP, bool SPL = false>
 __global__ void __launch_bounds__(64 * (TH / 4) * (BN >= 64 ? BN / 64 : 1))
 conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   constexpr int KC = 128 / (int)sizeof(T);
@@ -34,7 +36,8 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   constexpr int WBUF = BN * 128;
   constexpr int NPL = (PROWS * 8 + NTHR - 1) / NTHR;   // patch 16-byte items per thread
   constexpr int NWL = (BN * 8 + NTHR - 1) / NTHR;      // weight 16-byte items per thread
-  constexpr bool F32 = sizeof(T) == 4;
+  constexpr bool F32 = sizeof(T) == 4 && !SPL;
+  static_assert(!SPL || sizeof(T) == 4, "the split-precision mode stages f32 tensors");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* s_patch = smem;                          // 2 x PBUF
@@ -68,7 +71,10 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
     const int iy = y0 + pr - 1, ix = x0 + pc - 1;
     const bool ok = (q < PROWS * 8) && iy >= 0 && iy < H && ix >= 0 && ix < W;
     ppix[j] = min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1);
-    plds[j] = (q < PROWS * 8) ? prow * 128 + ((pch ^ ((pc >> 1) & 7)) << 4) : -1;     // swizzle key from the patch COLUMN (see a_base)
+    // swizzle key from the patch COLUMN (see a_base); split mode: the item's 4 channels are 8 bytes of the hi plane,
+    // their lo halves sit 64 bytes on (address ^ 64)
+    if constexpr (SPL) plds[j] = (q < PROWS * 8) ? prow * 128 + (((pch >> 1) ^ ((pc >> 1) & 7)) << 4) + (pch & 1) * 8 : -1;
+    else plds[j] = (q < PROWS * 8) ? prow * 128 + ((pch ^ ((pc >> 1) & 7)) << 4) : -1;
     pmask |= ok ? (1u << j) : 0u;
   }
   const int pchunk = tid & 7;          // NTHR is a multiple of 8: the 16-byte chunk is fixed per thread
@@ -116,7 +122,16 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
           v = gn_transform16<T>(v, s_gn + pgcb, s_gn + ((p.gn_C + 63) & ~63) + pgcb, p.gn_silu != 0);
       }
       if (!(((pmask >> j) & 1u) && pcok)) v = uint4{0u, 0u, 0u, 0u};   // padding AFTER the activation
-      if (plds[j] >= 0) *reinterpret_cast<uint4*>(P + plds[j]) = v;
+      if constexpr (SPL) {
+        uint2 hi, lo;
+        split_f16x4(*reinterpret_cast<const f32x4*>(&v), hi, lo);
+        if (plds[j] >= 0) {
+          *reinterpret_cast<uint2*>(P + plds[j]) = hi;
+          *reinterpret_cast<uint2*>(P + (plds[j] ^ 64)) = lo;
+        }
+      } else {
+        if (plds[j] >= 0) *reinterpret_cast<uint4*>(P + plds[j]) = v;
+      }
     }
   };
   auto write_patch = [&](int buf) __attribute__((always_inline)) {
@@ -190,13 +205,30 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
     {
       uint4 wf[NT], af[MT];
       const unsigned char* wsrc = Wt + (kk == 0 ? wb0 : wb1);
+      // (split mode: half 0 = w_hi . (a_hi, a_lo), half 1 = w_lo . a_hi)
       const unsigned char* asrc = P + dy * (PC * 128) +
-                                  (kk == 0 ? (dx == 0 ? ab00 : dx == 1 ? ab10 : ab20) : (dx == 0 ? ab01 : dx == 1 ? ab11 : ab21));
+                                  ((kk == 0 || SPL) ? (dx == 0 ? ab00 : dx == 1 ? ab10 : ab20) : (dx == 0 ? ab01 : dx == 1 ? ab11 : ab21));
 #pragma unroll
       for (int j = 0; j < NT; ++j) wf[j] = *reinterpret_cast<const uint4*>(wsrc + j * (16 * 128));
 #pragma unroll
       for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(asrc + i * (PC * 128));
-      if constexpr (!F32) {
+      if constexpr (SPL) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) Mfma<f16_t>::run(wf[j], af[i], acc[j][i]);
+        if (kk == 0) {
+          const unsigned char* lsrc = P + dy * (PC * 128) + (dx == 0 ? ab01 : dx == 1 ? ab11 : ab21);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const uint4*>(lsrc + i * (PC * 128));
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) Mfma<f16_t>::run(wf[j], af[i], acc[j][i]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+      } else if constexpr (!F32) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
@@ -310,6 +342,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + wn * (NT * 16) + j * 16 + fk * 4;
       float v[4] = {acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]};
+      if constexpr (SPL) { v[0] *= p.acc_scale; v[1] *= p.acc_scale; v[2] *= p.acc_scale; v[3] *= p.acc_scale; }
       const bool live = n < Cout;
       if (live) conv_epilogue4<TO>(p, m, b, n, v);
       if (do_stat && live) {
@@ -339,7 +372,7 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   }
 }
 
-template <typename T, typename TO, int TH, int BN, bool GNP>
+template <typename T, typename TO, int TH, int BN, bool GNP, bool SPL = false>
 static int launch_patch(const ConvParams& p, hipStream_t st) {
   constexpr int NTHR = 64 * (TH / 4) * (BN >= 64 ? BN / 64 : 1);
   constexpr int SMEM_MAX = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 8 + 64 * 4;
@@ -348,7 +381,7 @@ static int launch_patch(const ConvParams& p, hipStream_t st) {
   const int SMEM = 2 * (TH + 2) * 18 * 128 + 2 * BN * 128 + (GNP ? ((p.gn_C + 63) & ~63) * 8 : 0) + 64 * 8 + 64 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<T, TO, TH, BN, GNP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_patch_kernel<T, TO, TH, BN, GNP, SPL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_MAX);
     if (e != hipSuccess) {
       fdbm_set_error("fdbm_conv_igemm(patch): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -358,21 +391,21 @@ static int launch_patch(const ConvParams& p, hipStream_t st) {
   }
   const int tiles_x = p.W / 16, tiles_y = p.H / TH;
   dim3 grid((unsigned)(p.B * tiles_x * tiles_y), (unsigned)((p.Cout + BN - 1) / BN));
-  conv_patch_kernel<T, TO, TH, BN, GNP><<<grid, NTHR, SMEM, st>>>(p, tiles_x, tiles_y);
+  conv_patch_kernel<T, TO, TH, BN, GNP, SPL><<<grid, NTHR, SMEM, st>>>(p, tiles_x, tiles_y);
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm(patch)");
   return 0;
 }
 
-template <typename T, typename TO>
+template <typename T, typename TO, bool SPL = false>
 static int launch_patch_th(const ConvParams& p, int th, hipStream_t st) {
   const bool gnp = p.gn_sums != nullptr;
   if constexpr (sizeof(TO) == 4) {
     // the 4-channel heads (f32 output): 16-channel tiles, 8 rows (2 waves, 50 KiB of LDS: three workgroups share a CU
     // and the GroupNorm + SiLU of one's patch runs beside the others' MFMAs)
-    if (p.Cout <= 16) return gnp ? launch_patch<T, TO, 8, 16, true>(p, st) : launch_patch<T, TO, 8, 16, false>(p, st);
+    if (p.Cout <= 16) return gnp ? launch_patch<T, TO, 8, 16, true, SPL>(p, st) : launch_patch<T, TO, 8, 16, false, SPL>(p, st);
   }
-  if (th == 16) return gnp ? launch_patch<T, TO, 16, 128, true>(p, st) : launch_patch<T, TO, 16, 128, false>(p, st);
-  return gnp ? launch_patch<T, TO, 8, 128, true>(p, st) : launch_patch<T, TO, 8, 128, false>(p, st);
+  if (th == 16) return gnp ? launch_patch<T, TO, 16, 128, true, SPL>(p, st) : launch_patch<T, TO, 16, 128, false, SPL>(p, st);
+  return gnp ? launch_patch<T, TO, 8, 128, true, SPL>(p, st) : launch_patch<T, TO, 8, 128, false, SPL>(p, st);
 }
 
 // called from fdbm_conv_igemm (conv.hip) once it has validated the arguments and filled ConvParams
@@ -381,5 +414,6 @@ int fdbm_launch_conv_patch(const ConvParams& p, int dt_in, int dt_out, int th, h
   if (dt_in == FDBM_BF16 && dt_out == FDBM_F32) return launch_patch_th<bf16_t, float>(p, th, st);
   if (dt_in == FDBM_F16 && dt_out == FDBM_F16) return launch_patch_th<f16_t, f16_t>(p, th, st);
   if (dt_in == FDBM_F16 && dt_out == FDBM_F32) return launch_patch_th<f16_t, float>(p, th, st);
+  if (p.mma_split) return launch_patch_th<float, float, true>(p, th, st);
   return launch_patch_th<float, float>(p, th, st);
 }

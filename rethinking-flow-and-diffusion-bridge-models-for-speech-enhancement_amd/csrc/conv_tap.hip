@@ -49,7 +49,9 @@
 #define STAMP_RT(i)
 #endif
 
-template <typename T, typename TO, int TW, int MT, int NT, bool GNP>
+// SPL (T = float only): split-precision matrix mode - patch and weight rows hold [32 halves hi | 32 halves lo]
+// (conv_common.h), every product is three f16 MFMAs: hi.hi + hi.lo + lo.hi.
+template <typename T, typename TO, int TW, int MT, int NT, bool GNP, bool SPL = false>
 __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, int tiles_x, int tiles_y) {
   constexpr int KC = 128 / (int)sizeof(T);
   constexpr int VW = 16 / (int)sizeof(T);
@@ -61,7 +63,8 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   constexpr int NPL = (PROWS * 8 + TAP_NTHR - 1) / TAP_NTHR;
   constexpr int SLAB = MT * NT * 1024;       // one wave's accumulators: [MT*NT][64 lanes] f32x4
   constexpr int MAIN = (2 * PBUF > 4 * SLAB) ? 2 * PBUF : 4 * SLAB;
-  constexpr bool F32 = sizeof(T) == 4;
+  constexpr bool F32 = sizeof(T) == 4 && !SPL;
+  static_assert(!SPL || sizeof(T) == 4, "the split-precision mode stages f32 tensors");
   static_assert(NPL <= 4, "patch staging assumes at most 4 items per thread");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -94,7 +97,9 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
     const int iy = y0 + pr - 1, ix = x0 + pc - 1;
     const bool ok = (q < PROWS * 8) && iy >= 0 && iy < H && ix >= 0 && ix < W;
     ppix[j] = min(max(iy, 0), H - 1) * W + min(max(ix, 0), W - 1);
-    plds[j] = (q < PROWS * 8) ? prow * 128 + ((pch ^ ((prow >> 1) & 7)) << 4) : -1;
+    // (split mode: the item's 4 channels are 8 bytes of the hi plane; their lo halves sit 64 bytes on, address ^ 64)
+    if constexpr (SPL) plds[j] = (q < PROWS * 8) ? prow * 128 + (((pch >> 1) ^ ((prow >> 1) & 7)) << 4) + (pch & 1) * 8 : -1;
+    else plds[j] = (q < PROWS * 8) ? prow * 128 + ((pch ^ ((prow >> 1) & 7)) << 4) : -1;
     pmask |= ok ? (1u << j) : 0u;
   }
   const int pchunk = tid & 7;          // 512 % 8 == 0: the 16-byte chunk is fixed per thread
@@ -185,7 +190,16 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
           v = gn_transform16<T>(v, s_gn + pgcb, s_gn + CONV_GN_MAXC + pgcb, p.gn_silu != 0);
       }
       if (!(((pmask >> j) & 1u) && pcok)) v = uint4{0u, 0u, 0u, 0u};   // padding AFTER the activation
-      if (plds[j] >= 0) *reinterpret_cast<uint4*>(P + plds[j]) = v;
+      if constexpr (SPL) {
+        uint2 hi, lo;
+        split_f16x4(*reinterpret_cast<const f32x4*>(&v), hi, lo);
+        if (plds[j] >= 0) {
+          *reinterpret_cast<uint2*>(P + plds[j]) = hi;
+          *reinterpret_cast<uint2*>(P + (plds[j] ^ 64)) = lo;
+        }
+      } else {
+        if (plds[j] >= 0) *reinterpret_cast<uint4*>(P + plds[j]) = v;
+      }
     }
   };
   auto write_patch = [&](auto SET, int buf) __attribute__((always_inline)) {
@@ -219,7 +233,9 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
     for (int i = 0; i < MT; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   auto mma = [&](const uint4& wf, const uint4& af, f32x4& c) __attribute__((always_inline)) {
-    if constexpr (!F32) {
+    if constexpr (SPL) {
+      Mfma<f16_t>::run(wf, af, c);
+    } else if constexpr (!F32) {
       Mfma<T>::run(wf, af, c);
     } else {
 #pragma unroll
@@ -307,7 +323,10 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
       // all fragment reads of the chunk first (one LDS round trip instead of three), then its MFMAs, then the
       // reloads, then the next patch's items
       const int srow0 = crow0 + (t9 ? PCW + 1 : 0);       // shared tap: tap 8 of a 9-tap chunk, or the only tap of a 1-tap chunk
-      const uint4 afs = a_frag(P, srow0 + (MT >= 4 ? miw : 0) * MROW, kkw);
+      // (split mode: the k-half-0 waves multiply w_hi by a_hi and a_lo, the k-half-1 waves w_lo by a_hi)
+      const uint4 afs = a_frag(P, srow0 + (MT >= 4 ? miw : 0) * MROW, SPL ? 0 : kkw);
+      [[maybe_unused]] uint4 afs2 = afs;
+      if constexpr (SPL) afs2 = a_frag(P, srow0 + (MT >= 4 ? miw : 0) * MROW, 1);
       if (t9) {
         uint4 af0[MT < 2 ? 2 : MT], af1[MT < 2 ? 2 : MT];         // (not [1]: one-element arrays end up in scratch memory)
 #pragma unroll
@@ -319,13 +338,23 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
-          for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA1[j], wB1[j], wC1[j], wD1[j]), af1[i], acc[j][i]);
+          for (int i = 0; i < MT; ++i) {
+            if constexpr (SPL) {       // hi.hi above; w_hi.a_lo and w_lo.a_hi here
+              mma(SET_GET(S, wA0[j], wB0[j], wC0[j], wD0[j]), af1[i], acc[j][i]);
+              mma(SET_GET(S, wA1[j], wB1[j], wC1[j], wD1[j]), af0[i], acc[j][i]);
+            } else {
+              mma(SET_GET(S, wA1[j], wB1[j], wC1[j], wD1[j]), af1[i], acc[j][i]);
+            }
+          }
       }
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
         if ((i & 3) == miw) {
 #pragma unroll
-          for (int j = 0; j < NT; ++j) mma(SET_GET(S, wAs[j], wBs[j], wCs[j], wDs[j]), afs, acc[j][i]);
+          for (int j = 0; j < NT; ++j) {
+            mma(SET_GET(S, wAs[j], wBs[j], wCs[j], wDs[j]), afs, acc[j][i]);
+            if constexpr (SPL) { if (kkw == 0) mma(SET_GET(S, wAs[j], wBs[j], wCs[j], wDs[j]), afs2, acc[j][i]); }
+          }
         }
       }
 #pragma unroll
@@ -353,6 +382,14 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
         for (int j = 0; j < NT; ++j)
 #pragma unroll
           for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA0[j], wB0[j], wC0[j], wD0[j]), af[i], acc[j][i]);
+        if constexpr (SPL) {               // w_hi . a_lo while w_hi is still in its registers
+#pragma unroll
+          for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 1);
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) mma(SET_GET(S, wA0[j], wB0[j], wC0[j], wD0[j]), af[i], acc[j][i]);
+        }
       }
 #pragma unroll
       for (int j = 0; j < NT; ++j) {          // (1-tap chunks do not use the own-tap registers; they stay loaded)
@@ -363,7 +400,7 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
       if (t9) {
         uint4 af[MT < 2 ? 2 : MT];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, 1);
+        for (int i = 0; i < MT; ++i) af[i] = a_frag(P, arow0 + i * MROW, SPL ? 0 : 1);      // (split mode: w_lo . a_hi)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -380,9 +417,16 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
           if ((i & 3) == miw) {
-            const uint4 af = a_frag(P, srow0 + i * MROW, kkw);
+            const uint4 af = a_frag(P, srow0 + i * MROW, SPL ? 0 : kkw);
 #pragma unroll
             for (int j = 0; j < NT; ++j) mma(SET_GET(S, wAs[j], wBs[j], wCs[j], wDs[j]), af, acc[j][i]);
+            if constexpr (SPL) {
+              if (kkw == 0) {
+                const uint4 af2 = a_frag(P, srow0 + i * MROW, 1);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) mma(SET_GET(S, wAs[j], wBs[j], wCs[j], wDs[j]), af2, acc[j][i]);
+              }
+            }
           }
         }
 #pragma unroll
@@ -503,6 +547,7 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
         for (int r = 0; r < 4; ++r)
           s[r] += __hip_atomic_fetch_add(const_cast<float*>(src) + (int64_t)z * slab + r, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if constexpr (SPL) s *= p.acc_scale;
     float v[4] = {s[0], s[1], s[2], s[3]};
     const bool live = n < Cout;
     if (live) conv_epilogue4<TO>(p, m, b, n, v);
@@ -530,7 +575,7 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
   }
 }
 
-template <typename T, typename TO, int TW, int MT, int NT, bool GNP>
+template <typename T, typename TO, int TW, int MT, int NT, bool GNP, bool SPL = false>
 static int launch_tap(const ConvParams& p, hipStream_t st) {
   constexpr int RPM = 16 / TW, TR = MT * RPM;
   constexpr int PBUF = (TR + 2) * (TW + 2) * 128;
@@ -539,7 +584,7 @@ static int launch_tap(const ConvParams& p, hipStream_t st) {
   constexpr int SMEM = MAIN + (GNP ? CONV_GN_MAXC * 8 : 0) + 64 * 8 + 64 * 4 + 16;
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tap_kernel<T, TO, TW, MT, NT, GNP>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_tap_kernel<T, TO, TW, MT, NT, GNP, SPL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (e != hipSuccess) {
       fdbm_set_error("fdbm_conv_igemm(tap): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
@@ -549,24 +594,24 @@ static int launch_tap(const ConvParams& p, hipStream_t st) {
   }
   const int tiles_x = p.W / TW, tiles_y = p.H / TR;
   dim3 grid((unsigned)(p.B * tiles_x * tiles_y), (unsigned)((p.Cout + 16 * NT - 1) / (16 * NT)), (unsigned)p.ksplit);
-  conv_tap_kernel<T, TO, TW, MT, NT, GNP><<<grid, TAP_NTHR, SMEM, st>>>(p, tiles_x, tiles_y);
+  conv_tap_kernel<T, TO, TW, MT, NT, GNP, SPL><<<grid, TAP_NTHR, SMEM, st>>>(p, tiles_x, tiles_y);
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm(tap)");
   return 0;
 }
 
-template <typename T, typename TO, int TW, int MT>
+template <typename T, typename TO, int TW, int MT, bool SPL>
 static int launch_tap_nt(const ConvParams& p, int nt, hipStream_t st) {
   const bool gnp = p.gn_sums != nullptr;
-  if (nt == 4) return gnp ? launch_tap<T, TO, TW, MT, 4, true>(p, st) : launch_tap<T, TO, TW, MT, 4, false>(p, st);
-  if (nt == 2) return gnp ? launch_tap<T, TO, TW, MT, 2, true>(p, st) : launch_tap<T, TO, TW, MT, 2, false>(p, st);
-  return gnp ? launch_tap<T, TO, TW, MT, 1, true>(p, st) : launch_tap<T, TO, TW, MT, 1, false>(p, st);
+  if (nt == 4) return gnp ? launch_tap<T, TO, TW, MT, 4, true, SPL>(p, st) : launch_tap<T, TO, TW, MT, 4, false, SPL>(p, st);
+  if (nt == 2) return gnp ? launch_tap<T, TO, TW, MT, 2, true, SPL>(p, st) : launch_tap<T, TO, TW, MT, 2, false, SPL>(p, st);
+  return gnp ? launch_tap<T, TO, TW, MT, 1, true, SPL>(p, st) : launch_tap<T, TO, TW, MT, 1, false, SPL>(p, st);
 }
 
-template <typename T, typename TO>
+template <typename T, typename TO, bool SPL = false>
 static int launch_tap_shape(const ConvParams& p, int tw, int nt, hipStream_t st) {
-  if (tw == 16) return launch_tap_nt<T, TO, 16, 4>(p, nt, st);
-  if (tw == 8) return launch_tap_nt<T, TO, 8, 4>(p, nt, st);
-  return launch_tap_nt<T, TO, 4, 1>(p, nt, st);
+  if (tw == 16) return launch_tap_nt<T, TO, 16, 4, SPL>(p, nt, st);
+  if (tw == 8) return launch_tap_nt<T, TO, 8, 4, SPL>(p, nt, st);
+  return launch_tap_nt<T, TO, 4, 1, SPL>(p, nt, st);
 }
 
 // called from fdbm_conv_igemm (conv.hip) with validated arguments; tw = tile width, nt = n-tiles
@@ -575,5 +620,6 @@ int fdbm_launch_conv_tap(const ConvParams& p, int dt_in, int dt_out, int tw, int
   if (dt_in == FDBM_BF16 && dt_out == FDBM_F32) return launch_tap_shape<bf16_t, float>(p, tw, nt, st);
   if (dt_in == FDBM_F16 && dt_out == FDBM_F16) return launch_tap_shape<f16_t, f16_t>(p, tw, nt, st);
   if (dt_in == FDBM_F16 && dt_out == FDBM_F32) return launch_tap_shape<f16_t, float>(p, tw, nt, st);
+  if (p.mma_split) return launch_tap_shape<float, float, true>(p, tw, nt, st);
   return launch_tap_shape<float, float>(p, tw, nt, st);
 }

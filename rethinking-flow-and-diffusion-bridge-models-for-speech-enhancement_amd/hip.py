@@ -42,7 +42,8 @@ class ConvArgs(ctypes.Structure):
                 ("stat_out", c_void_p), ("stat_G", ctypes.c_int32), ("stat_nsplit", ctypes.c_int32),
                 ("w_frag", c_void_p),
                 ("gn_seg_sums", c_void_p * MAX_SEG), ("gn_seg_nsplit", ctypes.c_int32 * MAX_SEG),
-                ("acc_ws", c_void_p), ("acc_ws_bytes", c_i64), ("res_up2x", c_void_p)]
+                ("acc_ws", c_void_p), ("acc_ws_bytes", c_i64), ("res_up2x", c_void_p),
+                ("mma_mode", ctypes.c_int32), ("acc_scale", c_float)]
 
 
 class Op(ctypes.Structure):

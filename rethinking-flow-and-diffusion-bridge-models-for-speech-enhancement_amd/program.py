@@ -113,6 +113,23 @@ def frag_major(wpack):
     return wpack.view(nk, cp // 16, 16, 8, kc // 8).permute(0, 1, 3, 2, 4).contiguous()
 
 
+SPLIT_ACT_SCALE = 16.0      # csrc/conv_common.h
+
+
+def split_pack(wpack):
+    """[nk, CoutPad, 32] packed f32 weights -> ([nk, CoutPad, 64] float16 tensor whose rows are
+    [32 halves hi | 32 halves lo] of s_w * w, acc_scale = 1 / (16 s_w)); hi = half(s_w w) rounded to nearest,
+    lo = half(s_w w - hi): hi + lo carries 22 significant bits of every weight (include/fdbm_hip.h, mma_mode)."""
+    assert wpack.dtype == torch.float32 and wpack.shape[-1] == 32
+    amax = float(wpack.abs().max())
+    e = 0 if amax == 0.0 else 13 - math.floor(math.log2(amax))       # 2^13 <= s_w * amax < 2^14
+    sw = 2.0 ** e
+    scaled = wpack * sw                                              # exact (power of two)
+    hi = scaled.to(torch.float16)
+    lo = (scaled - hi.to(torch.float32)).to(torch.float16)
+    return torch.cat([hi, lo], dim=-1).contiguous(), 1.0 / (SPLIT_ACT_SCALE * sw)
+
+
 class Act:
     """An NHWC activation living in a pooled buffer."""
     __slots__ = ("t", "B", "H", "W", "C", "dtype", "ustats")
@@ -303,6 +320,18 @@ class Program:
             return True
         return segs[0][3] == 1 or a0.H * a0.W <= self.FUSE_PROLOGUE_MAX_HW
 
+    @staticmethod
+    def _seg_order_ok(segs):
+        """9-tap segments first, then 1-tap ones: what the wave-per-tap kernel needs (else fdbm_conv_igemm falls back to
+        the tap-outer kernel, which has no split-precision form)."""
+        seen1 = False
+        for (_, _, _, taps) in segs:
+            if taps == 1:
+                seen1 = True
+            elif seen1:
+                return False
+        return True
+
     def nk_of(self, segs):
         kc = hip.conv_kc(self.dtc)
         return sum(taps * ((cin + kc - 1) // kc) for (_, _, cin, taps) in segs)
@@ -320,8 +349,14 @@ class Program:
             ca.seg[i].src, ca.seg[i].C, ca.seg[i].coff, ca.seg[i].cin, ca.seg[i].taps = a.ptr, a.C, coff, cin, taps
             self.macs += a0.H * a0.W * cout * cin * taps
         ca.nseg = len(segs)
+        kind = self.plan(a0, cout, segs)["kind"]
+        if getattr(self.net, "split", False) and a0.dtype == torch.float32 and wpack.dtype == torch.float32 and kind in (1, 2) \
+                and self._seg_order_ok(segs):
+            # split-precision matrix mode: pre-split weights, three f16 MFMAs per product (fdbm_conv_args.mma_mode)
+            wpack, ca.acc_scale = self.net.split_weight(wpack)
+            ca.mma_mode = 1
         ca.w = wpack.data_ptr()
-        if self.plan(a0, cout, segs)["kind"] == 2:
+        if kind == 2:
             ca.w_frag = self.net.frag_weight(wpack).data_ptr()
             if self.fused and a0.M * cout * 4 <= (1 << 20):
                 # throughput mode: small-map convs may split their channel chunks over up to 8 workgroups that

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 import fdbm_amd  # noqa: F401
 from fdbm_amd import hip
-from fdbm_amd.program import pack_conv_weight, frag_major
+from fdbm_amd.program import pack_conv_weight, frag_major, split_pack
 from oracle import ncsnpp as onet
 
 pytestmark = pytest.mark.gpu
@@ -274,15 +274,31 @@ def test_pyramid_down_chain():
         cur = nxt
 
 
+F32S = "f32s"       # f32 tensors, split-precision matrix products (three f16 MFMAs over (hi, lo) operand pairs)
+
+
+def norm_dtype(dtype):
+    """-> (torch dtype, split mode)"""
+    return (torch.float32, True) if dtype == F32S else (dtype, False)
+
+
 def run_conv(segs_nchw, weights, bias, dtype, out_dtype=None, tbias=None, res=None, scale=1.0, splitk=False,
              gn=None, comb=None, stat_G=0, res_up=None):
-    """segs_nchw: list of (x NCHW cpu tensor, taps); weights: list of W [Cout, cin, k, k] per seg."""
-    out_dtype = out_dtype or dtype
+    """segs_nchw: list of (x NCHW cpu tensor, taps); weights: list of W [Cout, cin, k, k] per seg.
+    dtype F32S: f32 tensors in the split-precision matrix mode (fdbm_conv_args.mma_mode 1, pre-split weights)."""
+    dtype, split = norm_dtype(dtype)
+    out_dtype = norm_dtype(out_dtype)[0] if out_dtype is not None else dtype
     kc = hip.conv_kc(hip.dt_code(dtype))
     wpack, cpad = pack_conv_weight([(w, t) for w, (_, t) in zip(weights, segs_nchw)], kc, dtype, DEV)
     B, _, H, W = segs_nchw[0][0].shape
     cout = weights[0].shape[0]
     ca = hip.ConvArgs()
+    if split:
+        nk = sum(t * ((x.shape[1] + kc - 1) // kc) for (x, t) in segs_nchw)
+        if hip.conv_plan_ex(B, H, W, cout, nk, segs_nchw[0][1])["kind"] == 0:
+            pytest.skip("the split-precision mode is built for the halo-patch and wave-per-tap kernels (plan kinds 1, 2)")
+        wpack, ca.acc_scale = split_pack(wpack)
+        ca.mma_mode = 1
     keep = []
     for i, (x, taps) in enumerate(segs_nchw):
         d = nhwc(x, dtype)
@@ -404,10 +420,12 @@ def conv_kernels(request):
 
 
 @pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16, F32S])
 @pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
 def test_conv_igemm(case, dtype, splitk, conv_kernels):
     name, B, H, W, cins, cout, taps, extra = case
+    run_dtype = dtype
+    dtype = norm_dtype(dtype)[0]
     k = 3 if taps == 9 else 1
     xs = [rnd(B, c, H, W, seed=10 + i) for i, c in enumerate(cins)]
     ws = [rnd(cout, c, k, k, seed=20 + i) / math.sqrt(sum(cins) * taps) for i, c in enumerate(cins)]
@@ -442,7 +460,7 @@ def test_conv_igemm(case, dtype, splitk, conv_kernels):
         r = rnd(B, cout, H, W, seed=71)
         ref = ref + r
         kw.update(res=r, scale=1.0)
-    out, _, _ = run_conv(segs, weights, bias, dtype, out_dtype=out_dtype, splitk=splitk, **kw)
+    out, _, _ = run_conv(segs, weights, bias, run_dtype, out_dtype=out_dtype, splitk=splitk, **kw)
     assert not torch.isnan(out).any()
     err = (out - ref).abs().max().item()
     tol = 2e-5 if dtype == torch.float32 else (2e-2 if out_dtype == torch.bfloat16 else 4e-3 if out_dtype == torch.float16 else 2e-3)
@@ -472,7 +490,7 @@ def test_conv_full_size_linearity(dtype):
 
 
 @pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, F32S])
 @pytest.mark.parametrize("HW", [4, 8, 16], ids=["4x4", "8x8", "16x16"])
 @pytest.mark.parametrize("cin,cin1", [(64, 0), (128, 0), (192, 64), (320, 0), (384, 192), (448, 64), (576, 0)],
                          ids=["1", "2", "3+1", "5", "6+3", "7+1", "9"])
@@ -482,6 +500,8 @@ def test_conv_tap_chunk_remainders(cin, cin1, HW, dtype, splitk):
     remainder of the chunk count, with and without a 1-tap shortcut segment behind the 9-tap one, with the channel
     chunks split over workgroups (zeroed scratch) and not."""
     B, cout = 2, 32
+    run_dtype = dtype
+    dtype = norm_dtype(dtype)[0]
     x = rnd(B, cin, HW, HW, seed=cin + HW)
     w = rnd(cout, cin, 3, 3, seed=5) / math.sqrt(cin * 9)
     q = lambda t: t.to(dtype).float()
@@ -493,7 +513,7 @@ def test_conv_tap_chunk_remainders(cin, cin1, HW, dtype, splitk):
         ref = ref + F.conv2d(q(x1), q(w1))
         segs.append((x1, 1)); weights.append(w1)
     assert hip.conv_plan_ex(B, HW, HW, cout, 9 * ((cin + 63) // 64), 9)["kind"] == 2
-    out, _, _ = run_conv(segs, weights, None, dtype, splitk=splitk)
+    out, _, _ = run_conv(segs, weights, None, run_dtype, splitk=splitk)
     err = (out - ref).abs().max().item()
     assert err < (2e-5 if dtype == torch.float32 else 2e-2), err
 
@@ -517,12 +537,14 @@ FUSED_CASES = [
 
 @pytest.mark.parametrize("units", [False, True], ids=["groupstats", "unitstats"])
 @pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, F32S])
 @pytest.mark.parametrize("case", FUSED_CASES, ids=[c[0] for c in FUSED_CASES])
 def test_conv_fused_gn_combine_stats(case, dtype, splitk, conv_kernels, units):
     """conv3x3(silu(GroupNorm(cat(xs)))) [+ 1x1 shortcut of the raw input] [+ Combine] in one
     launch, plus the (sum, sumsq) of the stored output for the next GroupNorm."""
     name, B, H, W, cins, cout, G_in, G_out, shortcut, comb = case
+    run_dtype = dtype
+    dtype = norm_dtype(dtype)[0]
     xs = [rnd(B, c, H, W, seed=10 + i) * (1.5 if i == 0 else 0.7) + 0.2 * i for i, c in enumerate(cins)]
     q = lambda t: t.to(dtype).float()
     Cg = sum(cins)
@@ -557,7 +579,7 @@ def test_conv_fused_gn_combine_stats(case, dtype, splitk, conv_kernels, units):
         cp, cw, cb = rnd(B, 4, H, W, seed=60), rnd(cout, 4, seed=61), rnd(cout, seed=62)
         ref = ref + F.conv2d(cp, cw[:, :, None, None], cb)
         kw["comb"] = (cp, cw, cb)
-    out, _, st = run_conv(segs, weights, bias, dtype, splitk=splitk, **kw)
+    out, _, st = run_conv(segs, weights, bias, run_dtype, splitk=splitk, **kw)
     tol = 3e-5 if dtype == torch.float32 else 3e-2
     assert close(out, ref, tol), (name, float((out - ref).abs().max()))
     og = out.reshape(B, G_out, -1)                         # stats of what was stored

@@ -5,8 +5,9 @@ import torch
 import fdbm_amd
 from fdbm_amd import hip
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
-dtype = torch.bfloat16 if (len(sys.argv) < 3 or sys.argv[2] == "bf16") else torch.float32
-net = fdbm_amd.BackboneRegistry.get_by_name("ncsnpp_v2")(dtype=dtype, device="cuda:0")
+mode = sys.argv[2] if len(sys.argv) > 2 else "bf16"            # bf16 | f32 | f32s (f32 storage, split-precision matrix products)
+dtype = torch.bfloat16 if mode == "bf16" else torch.float32
+net = fdbm_amd.BackboneRegistry.get_by_name("ncsnpp_v2")(dtype=dtype, device="cuda:0", **(dict(split=True) if mode == "f32s" else {}))
 prog = net.program(B, 257, 256)
 prog.run(); torch.cuda.synchronize()
 names = {v: k for k, v in vars(hip).items() if k.startswith("OP_")}

@@ -13,14 +13,34 @@ import torch
 from .arch import Spec, VARIANTS
 
 
-def ema_state_dict(spec, shadow_params):
-    """torch_ema `shadow_params` (list in `parameters()` order) -> {backbone key: tensor}."""
-    order = spec.param_order()
-    shapes = spec.param_shapes()
-    if len(shadow_params) != len(order):
-        raise ValueError(f"EMA holds {len(shadow_params)} tensors, the backbone has {len(order)} parameters")
-    out = {}
-    for k, v in zip(order, shadow_params):
+# Parameters the reference creates with requires_grad=False: the fixed Fourier frequencies of the time embedding
+# (GaussianFourierProjection.W, layerspp.py:34) - `all_modules.0.W` in NCSN++, `get_time_emb.W` in TF-GridNet.
+FROZEN_KEYS = ("all_modules.0.W", "get_time_emb.W")
+
+
+def ema_state_dict(order, shapes, shadow_params, base=None):
+    """torch_ema `shadow_params` (a list in `parameters()` order) -> {backbone key: tensor}, ONE rule for every backbone
+    family.  The reference builds `ExponentialMovingAverage(self.parameters())` over whatever backbone it holds
+    (model.py:131-133); torch_ema releases differ in whether parameters with requires_grad=False get a shadow copy, and
+    the repository pins no version, so both layouts are accepted and told apart by their LENGTH:
+      * len == all parameters            -> `order` as it stands (unfiltered torch_ema),
+      * len == trainable parameters only -> `order` without FROZEN_KEYS; those tensors come from `base` (the raw
+                                            state_dict - they never change during training).
+    Every tensor's shape is checked against `shapes` either way."""
+    order = list(order)
+    trainable = [k for k in order if k not in FROZEN_KEYS]
+    if len(shadow_params) == len(order):
+        keys, out = order, {}
+    elif len(shadow_params) == len(trainable) and len(trainable) != len(order):
+        keys = trainable
+        frozen = [k for k in order if k in FROZEN_KEYS]
+        if base is None or any(k not in base for k in frozen):
+            raise ValueError(f"EMA holds the trainable parameters only; the frozen ones ({frozen}) must come from the state_dict")
+        out = {k: base[k] for k in frozen}
+    else:
+        raise ValueError(f"EMA holds {len(shadow_params)} tensors; the backbone has {len(order)} parameters "
+                         f"({len(trainable)} of them trainable)")
+    for k, v in zip(keys, shadow_params):
         if tuple(v.shape) != tuple(shapes[k]):
             raise ValueError(f"EMA tensor for {k}: shape {tuple(v.shape)} != expected {tuple(shapes[k])}")
         out[k] = v
@@ -47,19 +67,13 @@ def load_lightning_checkpoint(ckpt, use_ema=True):
     ema = ckpt.get("ema") if use_ema else None
     if ema is not None and ema.get("shadow_params") is not None:
         if name in TFG_VARIANTS:
-            # TF-GridNet: parameters() order = state-dict order (no buffers); the EMA tracks the trainable ones, i.e. all but
-            # the fixed Fourier frequencies get_time_emb.W (requires_grad=False, layerspp.py:34), which stay as stored
-            shapes = tfg_param_shapes(**TFG_VARIANTS[name])
-            order = [k for k in shapes if k != "get_time_emb.W"]
-            sp = ema["shadow_params"]
-            if len(sp) != len(order):
-                raise ValueError(f"EMA holds {len(sp)} tensors, the backbone has {len(order)} trainable parameters")
-            for k, v in zip(order, sp):
-                if tuple(v.shape) != tuple(shapes[k]):
-                    raise ValueError(f"EMA tensor for {k}: shape {tuple(v.shape)} != expected {tuple(shapes[k])}")
-                state[k] = v
+            shapes = tfg_param_shapes(**TFG_VARIANTS[name])         # parameters() order = state-dict order (no buffers)
+            order = list(shapes)
         else:
-            state = ema_state_dict(Spec(**VARIANTS[name]), ema["shadow_params"])
+            spec = Spec(**VARIANTS[name])
+            shapes, order = spec.param_shapes(), spec.param_order()
+        ema_state = ema_state_dict(order, shapes, ema["shadow_params"], base=state)
+        state = dict(state, **ema_state)
     return hp, state
 
 

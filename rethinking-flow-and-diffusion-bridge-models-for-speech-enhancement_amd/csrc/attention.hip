@@ -2,7 +2,7 @@
 //   out[b][i][:] = sum_j softmax_j(q_i . k_j * C^-0.5) v_j      over all N = H*W tokens.
 //
 // 0.04 % of the network's flops and latency-bound (N = T tokens at the 16-row level, 4*T/64
-// at the bottleneck).  Two kernels:
+// at the bottleneck).  The kernels:
 //  * attention_kernel: fp32 flash-style on the vector ALU (any N, C; the parity mode's kernel):
 //    16 queries per workgroup, keys/values streamed through LDS in tiles of 32, online softmax
 //    with 16-lane shuffle reductions, fp32 accumulation whatever the storage dtype.
@@ -382,6 +382,115 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
   }
 }
 
+// The parity modes' kernel where the shape allows (f32 storage, N % 64 == 0, N <= 512, C % 64 == 0): the structure of
+// attention_mfma_kernel on the f32 matrix instruction (v_mfma_f32_16x16x4_f32: exact f32 products and sums).  A b128
+// fragment is consumed as four k-groups - element q of lane (frow, fk) is channel / key 16 ks + 4 fk + q for BOTH
+// operands, so the same permutation of the reduction index on either side.  Scores, P and the V tile stay f32.
+// LDS rows: K tile [64 keys][C f32 + 16 B]; V^T tile [C channels][64 keys f32 + 16 B]; S [16][N] f32; P [16][N f32 + 16 B].
+__global__ void __launch_bounds__(256) attention_mfma_f32_kernel(float* __restrict__ out, const float* __restrict__ qkv,
+                                                                 int N, int C, float scale) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_f[];
+  const int KRS = C * 4 + 16;                 // K-tile row stride (bytes)
+  constexpr int VRS = 64 * 4 + 16;            // V^T-tile row stride
+  const int PRS = N * 4 + 16;                 // P row stride
+  const int kv_bytes = max(64 * KRS, C * VRS);
+  unsigned char* s_kv = smem_f;
+  float* s_S = reinterpret_cast<float*>(smem_f + kv_bytes);                 // [16][N]
+  unsigned char* s_P = smem_f + kv_bytes + 16 * N * 4;                      // [16][PRS]
+  const int b = blockIdx.y;
+  const int q0 = blockIdx.x * 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int frow = lane & 15, fk = lane >> 4;
+  const float* base = qkv + (int64_t)b * N * 3 * C;
+  const int nch = C / 4;                      // 16-byte chunks per row
+  const int nks = C / 16;                     // groups of four MFMA k-steps over the channels (<= 16)
+
+  // ---- Q tile -> LDS -> operand registers (B operand: column = query) ------------------------------
+  for (int i = tid; i < 16 * nch; i += 256) {
+    const int r = i / nch, ch = i - r * nch;
+    *reinterpret_cast<uint4*>(s_kv + r * KRS + ch * 16) =
+        *reinterpret_cast<const uint4*>(base + (int64_t)(q0 + r) * 3 * C + ch * 4);
+  }
+  __syncthreads();
+  f32x4 qf[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks)
+    qf[ks] = ks < nks ? *reinterpret_cast<const f32x4*>(s_kv + frow * KRS + (ks * 4 + fk) * 16) : f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+
+  // ---- scores: S[query][key] = scale * q . k, 64 keys per tile, 16 per wave ---------------------------
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    for (int i = tid; i < 64 * nch; i += 256) {
+      const int r = i / nch, ch = i - r * nch;
+      *reinterpret_cast<uint4*>(s_kv + r * KRS + ch * 16) =
+          *reinterpret_cast<const uint4*>(base + (int64_t)(k0 + r) * 3 * C + C + ch * 4);
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      if (ks < nks) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(s_kv + (wave * 16 + frow) * KRS + (ks * 4 + fk) * 16);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[q], qf[ks][q], acc, 0, 0, 0);   // rows = keys, columns = queries
+      }
+    *reinterpret_cast<f32x4*>(s_S + frow * N + k0 + wave * 16 + fk * 4) = acc * scale;
+    __syncthreads();
+  }
+
+  // ---- softmax over the N keys of each query: 16 threads per query ------------------------------------
+  {
+    const int q = tid >> 4, part = tid & 15;
+    const int per = N / 16;
+    const float* row = s_S + q * N + part * per;
+    float m = -INFINITY;
+    for (int i = 0; i < per; ++i) m = fmaxf(m, row[i]);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    float l = 0.f;
+    for (int i = 0; i < per; ++i) l += __expf(row[i] - m);
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) l += __shfl_xor(l, off);
+    const float inv = 1.0f / l;
+    float* prow = reinterpret_cast<float*>(s_P + q * PRS) + part * per;
+    for (int i = 0; i < per; ++i) prow[i] = __expf(row[i] - m) * inv;
+  }
+  __syncthreads();
+
+  // ---- O = P . V: wave w owns channels [w C/4, (w+1) C/4), 64 keys per tile -------------------------
+  const int ntw = C / 64;                     // 16-channel n-tiles per wave (<= 4)
+  f32x4 oacc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) oacc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < N; k0 += 64) {
+    // V tile transposed into LDS: a thread takes 4 channels of one key and writes them to 4 channel rows
+    for (int i = tid; i < 64 * nch; i += 256) {
+      const int ch = i % nch, key = i / nch;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)(k0 + key) * 3 * C + 2 * C + ch * 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) *reinterpret_cast<float*>(s_kv + (ch * 4 + e) * VRS + key * 4) = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const f32x4 pf = *reinterpret_cast<const f32x4*>(s_P + frow * PRS + (k0 + ks * 16 + fk * 4) * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < ntw) {
+          const int c = (wave * ntw + j) * 16 + frow;
+          const f32x4 vf = *reinterpret_cast<const f32x4*>(s_kv + c * VRS + (ks * 4 + fk) * 16);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) oacc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[q], pf[q], oacc[j], 0, 0, 0);   // rows = channels, columns = queries
+        }
+    }
+    __syncthreads();
+  }
+  float* dst = out + ((int64_t)b * N + q0 + frow) * C;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (j < ntw) *reinterpret_cast<f32x4*>(dst + (wave * ntw + j) * 16 + fk * 4) = oacc[j];
+}
+
 extern "C" int fdbm_attention(void* out, const void* qkv, int B, int N, int C, int dtype, void* stream) {
   FDBM_CHECK(out && qkv, "fdbm_attention: null pointer");
   FDBM_CHECK(C % 8 == 0 && C <= 256, "fdbm_attention: C=%d must be a multiple of 8, <= 256", C);
@@ -414,6 +523,13 @@ extern "C" int fdbm_attention(void* out, const void* qkv, int B, int N, int C, i
     ATT_16(bf16_t);
   } else if (dtype == FDBM_F16) {
     ATT_16(f16_t);
+  } else if (dtype == FDBM_F32 && N % 64 == 0 && N <= 512 && C % 64 == 0) {
+    const int krs = C * 4 + 16;
+    const size_t kv = (size_t)(64 * krs > C * 272 ? 64 * krs : C * 272);
+    const size_t sm = kv + (size_t)16 * N * 4 + (size_t)16 * (N * 4 + 16);
+    static bool setf = false;
+    if (!setf) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_mfma_f32_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); setf = true; }
+    attention_mfma_f32_kernel<<<dim3(N / 16, B), 256, sm, st>>>((float*)out, (const float*)qkv, N, C, scale);
   } else if (dtype == FDBM_F32) {
     static bool set = false;
     if (!set) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); set = true; }

@@ -695,6 +695,11 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     }
     p.gn_gamma = a->gn_gamma; p.gn_beta = a->gn_beta;
     p.gn_nsplit = a->gn_nsplit; p.gn_G = a->gn_G; p.gn_C = a->gn_C; p.gn_silu = a->gn_silu;
+    {
+      // split-precision mode: SiLU from the hardware exp2 / rcp (experiments: FDBM_SPLIT_SILU=precise = expf + division)
+      static const char* ss = getenv("FDBM_SPLIT_SILU");
+      if (p.mma_split && p.gn_silu && !(ss && ss[0] == 'p')) p.gn_silu = 2;
+    }
     p.gn_inv_count = 1.0 / (double)a->gn_count; p.gn_eps = a->gn_eps;
   }
   if (a->comb_pyr) {

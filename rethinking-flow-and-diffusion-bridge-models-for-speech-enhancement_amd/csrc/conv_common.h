@@ -293,7 +293,9 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
 
 // GroupNorm scale/shift (+ SiLU) of one 16-byte vector of activations (8 bf16 / 4 f32) whose first
 // channel's table entries are tsc[0] / tsh[0].
-template <typename T>
+// FAST (f32 tensors only): SiLU from the hardware exp2 / rcp (the 16-bit modes' form, ~3e-7 relative) instead of
+// expf and a true division - the split-precision mode's choice (FDBM_SPLIT_SILU=precise keeps the other).
+template <typename T, bool FAST = false>
 __device__ __forceinline__ uint4 gn_transform16(uint4 v, const float* tsc, const float* tsh, bool silu) {
   if constexpr (sizeof(T) == 2) {
     typename V16<T>::x8 e = *reinterpret_cast<typename V16<T>::x8*>(&v);
@@ -311,7 +313,9 @@ __device__ __forceinline__ uint4 gn_transform16(uint4 v, const float* tsc, const
     f32x4 e = *reinterpret_cast<f32x4*>(&v);
     if (silu) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) e[q] = silu_precise(e[q] * tsc[q] + tsh[q]);
+      for (int q = 0; q < 4; ++q) {
+        if constexpr (FAST) e[q] = silu_f(e[q] * tsc[q] + tsh[q]); else e[q] = silu_precise(e[q] * tsc[q] + tsh[q]);
+      }
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) e[q] = e[q] * tsc[q] + tsh[q];

@@ -119,7 +119,14 @@ conv_patch_kernel(const ConvParams p, int tiles_x, int tiles_y) {
       uint4 v = preg[j];
       if constexpr (GNP) {
         if (pgcb >= 0)                     // wave-uniform: a property of the segment
-          v = gn_transform16<T>(v, s_gn + pgcb, s_gn + ((p.gn_C + 63) & ~63) + pgcb, p.gn_silu != 0);
+        {
+          if constexpr (SPL) {
+            if (p.gn_silu == 2) v = gn_transform16<T, true>(v, s_gn + pgcb, s_gn + ((p.gn_C + 63) & ~63) + pgcb, true);
+            else v = gn_transform16<T>(v, s_gn + pgcb, s_gn + ((p.gn_C + 63) & ~63) + pgcb, p.gn_silu != 0);
+          } else {
+            v = gn_transform16<T>(v, s_gn + pgcb, s_gn + ((p.gn_C + 63) & ~63) + pgcb, p.gn_silu != 0);
+          }
+        }
       }
       if (!(((pmask >> j) & 1u) && pcok)) v = uint4{0u, 0u, 0u, 0u};   // padding AFTER the activation
       if constexpr (SPL) {

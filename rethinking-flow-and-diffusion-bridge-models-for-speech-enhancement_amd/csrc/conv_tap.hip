@@ -187,7 +187,14 @@ __global__ void __launch_bounds__(TAP_NTHR) conv_tap_kernel(const ConvParams p, 
       uint4 v = SET_GET(S, pregA[j], pregB[j], pregC[j], pregD[j]);
       if constexpr (GNP) {
         if (pgn)                           // wave-uniform: a property of the segment (scalar branch)
-          v = gn_transform16<T>(v, s_gn + pgcb, s_gn + CONV_GN_MAXC + pgcb, p.gn_silu != 0);
+        {
+          if constexpr (SPL) {
+            if (p.gn_silu == 2) v = gn_transform16<T, true>(v, s_gn + pgcb, s_gn + CONV_GN_MAXC + pgcb, true);
+            else v = gn_transform16<T>(v, s_gn + pgcb, s_gn + CONV_GN_MAXC + pgcb, p.gn_silu != 0);
+          } else {
+            v = gn_transform16<T>(v, s_gn + pgcb, s_gn + CONV_GN_MAXC + pgcb, p.gn_silu != 0);
+          }
+        }
       }
       if (!(((pmask >> j) & 1u) && pcok)) v = uint4{0u, 0u, 0u, 0u};   // padding AFTER the activation
       if constexpr (SPL) {

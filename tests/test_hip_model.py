@@ -21,18 +21,24 @@ def T(a):
 _CACHE = {}
 
 
-def net(name, dtype=torch.float32, fused=None):
-    key = (name, dtype, fused)
+def net(name, dtype=torch.float32, fused=None, split=False):
+    key = (name, dtype, fused, split)
     if key not in _CACHE:
         hp = MINI64 if name == "mini64" else VARIANTS[name]
-        _CACHE[key] = HipNCSNpp(dtype=dtype, device=DEV, fused=fused, **hp)
+        _CACHE[key] = HipNCSNpp(dtype=dtype, device=DEV, fused=fused, split=split, **hp)
     return _CACHE[key]
 
 
+@pytest.fixture(params=["f32", "f32s"])
+def split(request):
+    """f32 = exact f32 MFMA; f32s = f32 tensors, split-precision matrix products (fdbm_conv_args.mma_mode 1): same bars."""
+    return request.param == "f32s"
+
+
 @pytest.mark.parametrize("name,fix", [("mini64", "backbone_mini64"), ("ncsnpp_v2_5M", "backbone_v2_5M")])
-def test_backbone_fp32_vs_reference(golden, name, fix):
+def test_backbone_fp32_vs_reference(golden, name, fix, split):
     g = golden(fix)
-    out = net(name)(T(g["x"]).to(DEV), T(g["y"]).to(DEV), T(g["t"]).to(DEV)).cpu()
+    out = net(name, split=split)(T(g["x"]).to(DEV), T(g["y"]).to(DEV), T(g["t"]).to(DEV)).cpu()
     ref = T(g["out"])
     assert out.shape == ref.shape
     err = (out - ref).abs().max().item()
@@ -108,7 +114,7 @@ DIRECT_TOL = {"sb_bb_ode_ei_N5": 1.5e-3, "fm_ot_ode_ei_N5": 2e-4, "sb_bb_sde_ei_
 
 @pytest.mark.parametrize("use_graph", [False, True])
 @pytest.mark.parametrize("tag,bkw,skw", SAMPLERS, ids=[s[0] for s in SAMPLERS])
-def test_samplers_vs_reference(golden, tag, bkw, skw, use_graph):
+def test_samplers_vs_reference(golden, tag, bkw, skw, use_graph, split):
     """Identical (noisy_spec, seed, N) -> final complex spectrogram.
     (1) direct: max-abs vs the reference within DIRECT_TOL;
     (2) arbiter: the HIP result is no farther from the fp64 trajectory than the reference is
@@ -117,7 +123,7 @@ def test_samplers_vs_reference(golden, tag, bkw, skw, use_graph):
     y = T(g["y"]).to(DEV)
     br = fdbm_amd.Bridge(**bkw)
     gen = torch.Generator().manual_seed(1234)               # the reference ran torch.manual_seed(1234) on CPU
-    out = br.sampler(net("ncsnpp_v2_5M"), y, generator=gen, use_graph=use_graph, **skw).cpu()
+    out = br.sampler(net("ncsnpp_v2_5M", split=split), y, generator=gen, use_graph=use_graph, **skw).cpu()
     ref = T(g[tag])
     err = (out - ref).abs().max().item()
     tol = DIRECT_TOL[tag] if DIRECT_TOL[tag] is not None else 1e-5 * ref.abs().max().item()

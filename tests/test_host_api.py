@@ -180,11 +180,40 @@ def test_lightning_checkpoint_import(tmp_path):
     assert set(state) == set(raw) and all(torch.equal(state[k], ema[k]) for k in raw)          # EMA weights by default
     _, state_raw = load_lightning_checkpoint(str(path), use_ema=False)
     assert all(torch.equal(state_raw[k], raw[k]) for k in raw)
-    bad = dict(ckpt, ema={"shadow_params": ckpt["ema"]["shadow_params"][:-1]})
+    bad = dict(ckpt, ema={"shadow_params": ckpt["ema"]["shadow_params"][:-2]})
     with pytest.raises(ValueError):
         load_lightning_checkpoint(bad)
     with pytest.raises(KeyError):
         load_lightning_checkpoint({"hyper_parameters": {}})
+    # the other torch_ema layout: shadow copies of the TRAINABLE parameters only (the fixed Fourier frequencies
+    # all_modules.0.W, requires_grad=False, are then taken from the state_dict) - same rule for both backbone families
+    trainable = dict(ckpt, ema={"shadow_params": [ema[k] for k in spec.param_order() if k != "all_modules.0.W"]})
+    _, st = load_lightning_checkpoint(trainable)
+    assert torch.equal(st["all_modules.0.W"], raw["all_modules.0.W"])
+    assert all(torch.equal(st[k], ema[k]) for k in raw if k != "all_modules.0.W")
+    swapped = dict(ckpt, ema={"shadow_params": list(reversed(ckpt["ema"]["shadow_params"]))})
+    with pytest.raises(ValueError):                    # right count, wrong order: caught by the shape check
+        load_lightning_checkpoint(swapped)
+
+
+def test_lightning_checkpoint_import_tfgridnet_both_ema_layouts():
+    """TF-GridNet checkpoints under the same rule: shadow_params of all parameters (incl. the frozen
+    get_time_emb.W) or of the trainable ones only."""
+    import torch
+    from fdbm_amd import tfgridnet as tg
+    from fdbm_amd.checkpoint import load_lightning_checkpoint
+    name = "tfgridnet_4l32c80"
+    shapes = tg.param_shapes(**tg.VARIANTS[name])
+    raw = {k: torch.from_numpy(np.asarray(v)) for k, v in tg.fill_state(shapes, seed=5).items()}
+    ema = {k: torch.from_numpy(np.asarray(v)) for k, v in tg.fill_state(shapes, seed=6).items()}
+    base = {"state_dict": {"dnn." + k: v for k, v in raw.items()}, "hyper_parameters": {"backbone": name}}
+    _, st = load_lightning_checkpoint(dict(base, ema={"shadow_params": [ema[k] for k in shapes]}))
+    assert all(torch.equal(st[k], ema[k]) for k in shapes)
+    _, st = load_lightning_checkpoint(dict(base, ema={"shadow_params": [ema[k] for k in shapes if k != "get_time_emb.W"]}))
+    assert torch.equal(st["get_time_emb.W"], raw["get_time_emb.W"])
+    assert all(torch.equal(st[k], ema[k]) for k in shapes if k != "get_time_emb.W")
+    with pytest.raises(ValueError):
+        load_lightning_checkpoint(dict(base, ema={"shadow_params": [ema[k] for k in list(shapes)[:-3]]}))
 
 
 def test_infer_driver_file_side(tmp_path):

@@ -75,6 +75,32 @@ int fdbm_langevin_step(float* step /*[B]*/, float* noise_scale /*[B]*/, void* sc
                        const void* y, const void* noise, const float* a, const float* b, const float* den,
                        float snr, int B, int64_t n_complex, void* stream);
 
+/* ------------------------------------------------------------------ Gaussian noise on the device
+ * The per-step draws of the stochastic samplers (torch.randn_like of the complex state: fdbm/bridge.py:47,108,
+ * fdbm/util/predictors.py:46, fdbm/util/correctors.py:48,76) from a COUNTER-BASED generator, so that the kernel that
+ * consumes a draw generates it in registers: no host generator, no noise tensors in HBM.
+ * Complex element e (flat index into the [B][1][F][T] state) of draw d under seed s:
+ *     (x0, x1, ., .) = Philox4x32-10(counter = (e_lo, e_hi, d, 0x46444d42), key = (s_lo, s_hi))
+ *     u1 = ((x0 >> 8) + 0.5) 2^-24,  u2 = ((x1 >> 8) + 0.5) 2^-24
+ *     r = sqrt(-2 ln u1);  re = r cos(2 pi u2) sqrt(1/2);  im = r sin(2 pi u2) sqrt(1/2)        (Re, Im ~ N(0, 1/2))
+ * (restated in numpy, with Random123's known-answer vectors: oracle/rng.py).  rng = three DEVICE words {s_lo, s_hi, d_base};
+ * the draw used is d_base + `draw` (a sampler numbers its draws in call order: 0 = prior, 1.. = the steps'), so a
+ * captured graph keeps its literal `draw` arguments while the host moves d_base / the seed between replays.
+ * fdbm_randn_complex materialises one draw; the *_rng forms of the sampler kernels below take (rng, draw) in place of
+ * their noise pointer and are bit-identical to feeding them fdbm_randn_complex's tensor.  Parity with the reference's
+ * own generator is a matter of injected noise tensors (hard part 3), not of this stream. */
+int fdbm_randn_complex(void* out /*c64 [n_complex]*/, int64_t n_complex, const uint32_t* rng, uint32_t draw, void* stream);
+int fdbm_step_boundary_rng(void* x, const void* y, const uint32_t* rng, uint32_t draw, const float* pyramid,
+                           const float* out_w, const float* out_b, const float* wa, const float* wb, const float* wc,
+                           float* packed, void* zero_ptr, int64_t zero_bytes, float* dense_dst, const float* dense_src,
+                           int64_t dense_n, int B, int F, int Fn, int T, void* stream);
+int fdbm_pc_predictor_rng(void* x_new, void* x_mean, const void* x, const void* s, const void* y,
+                          const uint32_t* rng, uint32_t draw, const float* wx, const float* ws, const float* wy,
+                          const float* gd, float dt, int B, int64_t n_complex, void* stream);
+int fdbm_pc_corrector_rng(void* x_new, void* x_mean, const void* x, const void* s, const void* y,
+                          const uint32_t* rng, uint32_t draw, const float* a, const float* b, const float* den,
+                          const float* step, const float* noise_scale, int B, int64_t n_complex, void* stream);
+
 /* ------------------------------------------------------------------ network input / output
  * cat(x.re, x.im, y.re, y.im) with the Nyquist row dropped when F == 257
  * (fdbm/backbones/ncsnpp_v2.py:247-250): complex64 [B][1][F][T] x2 -> f32 [B][Fn][T][4]. */

@@ -46,20 +46,50 @@ def complex_randn(shape, generator=None, device=None):
     return z.to(device) if device is not None else z
 
 
+def rng_state(seed, device, base=0):
+    """The three device words {seed_lo, seed_hi, draw_base} the library's counter-based generator reads
+    (include/fdbm_hip.h, "Gaussian noise on the device")."""
+    import numpy as np
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    words = np.array([seed & 0xFFFFFFFF, seed >> 32, base & 0xFFFFFFFF, 0], dtype=np.uint32).view(np.int32)
+    return torch.from_numpy(words.copy()).to(device)
+
+
 class NoiseSource:
     """Hands out the complex Gaussian tensors a sampler consumes, in call order.
 
     Priority: explicit tensors (``prior_noise`` / ``step_noise`` list or callable)
-    > host ``generator`` > the device's default generator (``torch.randn_like``,
-    i.e. exactly what the reference does on that device).
+    > host ``generator`` > ``device_seed`` (the library's counter-based generator on the HIP device: draw 0 = the
+    prior, draw 1 + i = the i-th step draw; the graph samplers then generate each draw inside the kernel that
+    consumes it) > the device's default generator (``torch.randn_like``, i.e. exactly what the reference does on that
+    device).
     """
 
-    def __init__(self, like, prior_noise=None, step_noise=None, generator=None):
+    def __init__(self, like, prior_noise=None, step_noise=None, generator=None, device_seed=None):
         self.like = like
         self.prior_noise = prior_noise
         self.step_noise = step_noise
         self.generator = generator
+        self.device_seed = None
+        if device_seed is not None and prior_noise is None and step_noise is None and generator is None:
+            if not like.is_cuda:
+                raise RuntimeError("device_seed draws the noise on the HIP device; the state is a host tensor")
+            self.device_seed = int(device_seed)
+            self._rng = None
         self.calls = 0
+
+    @property
+    def in_kernel(self):
+        """True when the draws can be generated inside the consuming kernels (device_seed given, nothing injected)."""
+        return self.device_seed is not None
+
+    def _device_draw(self, draw):
+        from . import hip
+        if self._rng is None:
+            self._rng = rng_state(self.device_seed, self.like.device)
+        out = torch.empty_like(self.like, dtype=torch.complex64)
+        hip.call("fdbm_randn_complex", out.data_ptr(), out.numel(), self._rng.data_ptr(), draw)
+        return out
 
     def _draw(self):
         if self.generator is not None:
@@ -69,6 +99,8 @@ class NoiseSource:
     def prior(self):
         if self.prior_noise is not None:
             return self.prior_noise.to(self.like.device)
+        if self.device_seed is not None:
+            return self._device_draw(0)
         return self._draw()
 
     def step(self):
@@ -77,6 +109,8 @@ class NoiseSource:
         if self.step_noise is not None:
             z = self.step_noise(i) if callable(self.step_noise) else self.step_noise[i]
             return z.to(self.like.device)
+        if self.device_seed is not None:
+            return self._device_draw(1 + i)
         return self._draw()
 
 
@@ -136,6 +170,11 @@ class Bridge:
         noise = noise or NoiseSource(y)
         t0 = self.start_time * torch.ones((y.shape[0],))
         _, b0, sig0 = self.path.path_param(t0)
+        if noise.in_kernel and y.is_cuda and not bool(sig0.any()):
+            # sb: sigma(t0) = 0, the draw would be multiplied by zero.  With the counter-based device generator nothing
+            # depends on "advancing" a generator state (draw 0 simply stays unused), so it is not made at all.
+            from . import hip
+            return hip.bridge_update(y, y, None, b0, sig0, None)
         z = noise.prior()
         if y.is_cuda:
             from . import hip
@@ -177,7 +216,7 @@ class Bridge:
     @staticmethod
     def _noise(y, kwargs):
         return NoiseSource(y, kwargs.pop("prior_noise", None), kwargs.pop("step_noise", None),
-                           kwargs.pop("generator", None))
+                           kwargs.pop("generator", None), kwargs.pop("device_seed", None))
 
     # ---- exponential-integrator samplers ---------------------------------
     def ode_sampler_ei(self, model, y, **kwargs):

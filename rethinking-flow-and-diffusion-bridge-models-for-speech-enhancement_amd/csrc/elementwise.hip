@@ -70,14 +70,70 @@ extern "C" int fdbm_bridge_update(void* out, const void* a, const void* b, const
 }
 
 // ---------------------------------------------------------------------------------
+// counter-based Gaussian noise (the per-step draws of the stochastic samplers: torch.randn_like in
+// fdbm/bridge.py:47,108, fdbm/util/predictors.py:46, fdbm/util/correctors.py:48,76) generated ON the device, in
+// registers, by the kernel that consumes it - no host generator, no N x B noise tensors uploaded before a replay.
+// Definition (also restated in numpy: oracle/rng.py).  Complex element e (flat index into the [B,1,F,T] state) of
+// draw d under seed s:
+//     (x0, x1, x2, x3) = Philox4x32-10(counter = (e_lo, e_hi, d, 0x46444d42), key = (s_lo, s_hi))
+//     u1 = ((x0 >> 8) + 0.5) 2^-24,  u2 = ((x1 >> 8) + 0.5) 2^-24          (both in (0, 1))
+//     r = sqrt(-2 ln u1),  re = r cos(2 pi u2) sqrt(1/2),  im = r sin(2 pi u2) sqrt(1/2)
+// i.e. Re, Im ~ N(0, 1/2) like torch.randn_like of a complex64 tensor.  A draw is named by its index d in the
+// sampler's call order (0 = the prior, then the per-step draws); rng = device words {s_lo, s_hi, d_base}: d = d_base +
+// the draw argument, so successive sampler calls continue the stream without re-capturing their graph.
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t& o0, uint32_t& o1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o0 = c0; o1 = c1;
+  (void)c2; (void)c3;
+}
+
+__device__ __forceinline__ f32x2 rng_complex_normal(int64_t e, uint32_t draw, uint32_t s_lo, uint32_t s_hi) {
+  uint32_t x0, x1;
+  philox4x32_10((uint32_t)(uint64_t)e, (uint32_t)((uint64_t)e >> 32), draw, 0x46444d42u, s_lo, s_hi, x0, x1);
+  const float u1 = ((float)(x0 >> 8) + 0.5f) * 5.9604644775390625e-08f;
+  const float u2 = ((float)(x1 >> 8) + 0.5f) * 5.9604644775390625e-08f;
+  const float r = sqrtf(-2.0f * logf(u1));
+  float sn, cs;
+  sincosf(6.283185307179586f * u2, &sn, &cs);
+  return f32x2{(r * cs) * 0.7071067811865476f, (r * sn) * 0.7071067811865476f};
+}
+
+__global__ void __launch_bounds__(256) randn_complex_kernel(f32x2* __restrict__ out, int64_t n, const uint32_t* __restrict__ rng,
+                                                            uint32_t draw) {
+  const uint32_t s_lo = rng[0], s_hi = rng[1], d = rng[2] + draw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = rng_complex_normal(i, d, s_lo, s_hi);
+}
+
+extern "C" int fdbm_randn_complex(void* out, int64_t n_complex, const uint32_t* rng, uint32_t draw, void* stream) {
+  FDBM_CHECK(out && rng && n_complex >= 0, "fdbm_randn_complex: null pointer / bad size");
+  if (n_complex == 0) return 0;
+  int g = (int)((n_complex + 255) / 256);
+  if (g > 4096) g = 4096;
+  randn_complex_kernel<<<g, 256, 0, (hipStream_t)stream>>>((f32x2*)out, n_complex, rng, draw);
+  FDBM_LAUNCH_CHECK("fdbm_randn_complex");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // step boundary of the exponential-integrator samplers inside a replayed graph: what sits between two backbone
 // evaluations - unpack_output (pyramid -> score, ncsnpp_v2.py:391-399), the state update (fdbm_bridge_update), the
 // next evaluation's pack_input, the zeroing of its statistics arena and the copy of its time-embedding rows - as ONE
 // launch instead of five (each 4-5 us of launch floor at batch 1).  Elementwise in (b, f, t); the arithmetic of the
 // score and of the update is the two kernels' own, expression for expression (bit-identical results).
 // ---------------------------------------------------------------------------------
+// RNG: `third` is the step's Gaussian noise, generated here (rng_complex_normal) instead of read
+template <bool RNG>
 __global__ void __launch_bounds__(256) step_boundary_kernel(
-    f32x2* __restrict__ x, const f32x2* __restrict__ y, const f32x2* __restrict__ third,
+    f32x2* __restrict__ x, const f32x2* __restrict__ y, const f32x2* __restrict__ third, const uint32_t* __restrict__ rng, uint32_t draw,
     const f32x4* __restrict__ pyr, const float* __restrict__ ow, const float* __restrict__ ob,
     const float* __restrict__ wa, const float* __restrict__ wb, const float* __restrict__ wc,
     f32x4* __restrict__ inp, uint4* __restrict__ zero16, int64_t nzero16,
@@ -85,6 +141,8 @@ __global__ void __launch_bounds__(256) step_boundary_kernel(
     int F, int Fn, int T, int64_t total) {
   const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gstride = (int64_t)gridDim.x * blockDim.x;
   float w00 = 0, w01 = 0, w02 = 0, w03 = 0, w10 = 0, w11 = 0, w12 = 0, w13 = 0, b0 = 0, b1 = 0;
+  uint32_t s_lo = 0, s_hi = 0, dr = 0;
+  if constexpr (RNG) { s_lo = rng[0]; s_hi = rng[1]; dr = rng[2] + draw; }
   if (pyr) {
     w00 = ow[0]; w01 = ow[1]; w02 = ow[2]; w03 = ow[3];
     w10 = ow[4]; w11 = ow[5]; w12 = ow[6]; w13 = ow[7];
@@ -105,7 +163,8 @@ __global__ void __launch_bounds__(256) step_boundary_kernel(
         o[1] = b1 + (((w10 * p[0] + w11 * p[1]) + w12 * p[2]) + w13 * p[3]);
       }
       const float fa = wa[b], fb = wb[b], fc = wc[b];
-      const f32x2 cv = third[i];
+      f32x2 cv;
+      if constexpr (RNG) cv = rng_complex_normal(i, dr, s_lo, s_hi); else cv = third[i];
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         float sv = __fadd_rn(__fmul_rn(fa, xv[k]), __fmul_rn(fb, o[k]));
@@ -123,33 +182,59 @@ __global__ void __launch_bounds__(256) step_boundary_kernel(
   for (int64_t i = gtid; i < ndense; i += gstride) dense_dst[i] = dense_src[i];
 }
 
-extern "C" int fdbm_step_boundary(void* x, const void* y, const void* third, const float* pyramid, const float* out_w,
-                                  const float* out_b, const float* wa, const float* wb, const float* wc, float* packed,
-                                  void* zero_ptr, int64_t zero_bytes, float* dense_dst, const float* dense_src,
-                                  int64_t dense_n, int B, int F, int Fn, int T, void* stream) {
+static int step_boundary_impl(void* x, const void* y, const void* third, const uint32_t* rng, uint32_t draw, const float* pyramid,
+                              const float* out_w, const float* out_b, const float* wa, const float* wb, const float* wc, float* packed,
+                              void* zero_ptr, int64_t zero_bytes, float* dense_dst, const float* dense_src,
+                              int64_t dense_n, int B, int F, int Fn, int T, void* stream) {
   FDBM_CHECK(x && y, "fdbm_step_boundary: null state");
-  FDBM_CHECK(!pyramid || (third && out_w && out_b && wa && wb && wc), "fdbm_step_boundary: the update needs third, out_w, out_b, wa, wb, wc");
+  FDBM_CHECK(!pyramid || ((third || rng) && out_w && out_b && wa && wb && wc), "fdbm_step_boundary: the update needs third (or rng), out_w, out_b, wa, wb, wc");
   FDBM_CHECK(B > 0 && Fn > 0 && Fn <= F && T > 0, "fdbm_step_boundary: bad shape");
   FDBM_CHECK(zero_bytes >= 0 && zero_bytes % 16 == 0 && (((uintptr_t)zero_ptr) & 15) == 0, "fdbm_step_boundary: the zeroed range must be 16-byte aligned and sized");
   FDBM_CHECK(dense_n >= 0 && (dense_n == 0 || (dense_dst && dense_src)), "fdbm_step_boundary: bad time-embedding rows");
   const int64_t total = (int64_t)B * F * T;
   int g = (int)((total + 255) / 256);
   if (g > 4096) g = 4096;
-  step_boundary_kernel<<<g, 256, 0, (hipStream_t)stream>>>(
-      (f32x2*)x, (const f32x2*)y, (const f32x2*)third, (const f32x4*)pyramid, out_w, out_b, wa, wb, wc, (f32x4*)packed,
-      (uint4*)zero_ptr, zero_ptr ? zero_bytes / 16 : 0, dense_dst, dense_src, dense_n, F, Fn, T, total);
+  if (rng)
+    step_boundary_kernel<true><<<g, 256, 0, (hipStream_t)stream>>>(
+        (f32x2*)x, (const f32x2*)y, nullptr, rng, draw, (const f32x4*)pyramid, out_w, out_b, wa, wb, wc, (f32x4*)packed,
+        (uint4*)zero_ptr, zero_ptr ? zero_bytes / 16 : 0, dense_dst, dense_src, dense_n, F, Fn, T, total);
+  else
+    step_boundary_kernel<false><<<g, 256, 0, (hipStream_t)stream>>>(
+        (f32x2*)x, (const f32x2*)y, (const f32x2*)third, nullptr, 0u, (const f32x4*)pyramid, out_w, out_b, wa, wb, wc, (f32x4*)packed,
+        (uint4*)zero_ptr, zero_ptr ? zero_bytes / 16 : 0, dense_dst, dense_src, dense_n, F, Fn, T, total);
   FDBM_LAUNCH_CHECK("fdbm_step_boundary");
   return 0;
+}
+
+extern "C" int fdbm_step_boundary(void* x, const void* y, const void* third, const float* pyramid, const float* out_w,
+                                  const float* out_b, const float* wa, const float* wb, const float* wc, float* packed,
+                                  void* zero_ptr, int64_t zero_bytes, float* dense_dst, const float* dense_src,
+                                  int64_t dense_n, int B, int F, int Fn, int T, void* stream) {
+  return step_boundary_impl(x, y, third, nullptr, 0u, pyramid, out_w, out_b, wa, wb, wc, packed, zero_ptr, zero_bytes, dense_dst,
+                            dense_src, dense_n, B, F, Fn, T, stream);
+}
+
+extern "C" int fdbm_step_boundary_rng(void* x, const void* y, const uint32_t* rng, uint32_t draw, const float* pyramid,
+                                      const float* out_w, const float* out_b, const float* wa, const float* wb, const float* wc,
+                                      float* packed, void* zero_ptr, int64_t zero_bytes, float* dense_dst, const float* dense_src,
+                                      int64_t dense_n, int B, int F, int Fn, int T, void* stream) {
+  FDBM_CHECK(rng, "fdbm_step_boundary_rng: null rng state");
+  return step_boundary_impl(x, y, nullptr, rng, draw, pyramid, out_w, out_b, wa, wb, wc, packed, zero_ptr, zero_bytes, dense_dst,
+                            dense_src, dense_n, B, F, Fn, T, stream);
 }
 
 // ---------------------------------------------------------------------------------
 // predictor / corrector moves
 // ---------------------------------------------------------------------------------
+// RNG (here and in the corrector): float i of sample bi is component (i & 1) of complex element (bi nfloat + i) / 2 of the draw
+template <bool RNG>
 __global__ void __launch_bounds__(256) pc_predictor_kernel(
     float* __restrict__ xn, float* __restrict__ xm, const float* __restrict__ x,
-    const float* __restrict__ s, const float* __restrict__ y, const float* __restrict__ z,
+    const float* __restrict__ s, const float* __restrict__ y, const float* __restrict__ z, const uint32_t* __restrict__ rng, uint32_t draw,
     const float* wx, const float* ws, const float* wy, const float* gd, float dt, float sq,
     int64_t nfloat) {
+  uint32_t s_lo = 0, s_hi = 0, dr = 0;
+  if constexpr (RNG) { s_lo = rng[0]; s_hi = rng[1]; dr = rng[2] + draw; }
   const int bi = blockIdx.y;
   const float fx = wx[bi], fs = ws[bi], fy = wy[bi];
   const float gz = __fmul_rn(gd[bi], sq);
@@ -161,32 +246,56 @@ __global__ void __launch_bounds__(256) pc_predictor_kernel(
                             __fmul_rn(fy, y[base + i]));
     float mean = __fadd_rn(xv, __fmul_rn(drift, dt));
     xm[base + i] = mean;
-    xn[base + i] = __fadd_rn(mean, __fmul_rn(gz, z[base + i]));
+    float zv;
+    if constexpr (RNG) zv = rng_complex_normal((base + i) >> 1, dr, s_lo, s_hi)[i & 1]; else zv = z[base + i];
+    xn[base + i] = __fadd_rn(mean, __fmul_rn(gz, zv));
   }
+}
+
+static int pc_predictor_impl(void* x_new, void* x_mean, const void* x, const void* s,
+                             const void* y, const void* z, const uint32_t* rng, uint32_t draw, const float* wx, const float* ws,
+                             const float* wy, const float* gd, float dt, int B,
+                             int64_t n_complex, void* stream) {
+  FDBM_CHECK(x_new && x_mean && x && s && y && (z || rng) && wx && ws && wy && gd, "fdbm_pc_predictor: null pointer");
+  FDBM_CHECK(dt <= 0.f, "fdbm_pc_predictor: dt must be <= 0 (reverse time), got %g", dt);
+  const int64_t nfloat = 2 * n_complex;
+  int gx = (int)((nfloat + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  if (gx < 1) gx = 1;
+  if (rng)
+    pc_predictor_kernel<true><<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(
+        (float*)x_new, (float*)x_mean, (const float*)x, (const float*)s, (const float*)y,
+        nullptr, rng, draw, wx, ws, wy, gd, dt, sqrtf(-dt), nfloat);
+  else
+    pc_predictor_kernel<false><<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(
+        (float*)x_new, (float*)x_mean, (const float*)x, (const float*)s, (const float*)y,
+        (const float*)z, nullptr, 0u, wx, ws, wy, gd, dt, sqrtf(-dt), nfloat);
+  FDBM_LAUNCH_CHECK("fdbm_pc_predictor");
+  return 0;
 }
 
 extern "C" int fdbm_pc_predictor(void* x_new, void* x_mean, const void* x, const void* s,
                                  const void* y, const void* z, const float* wx, const float* ws,
                                  const float* wy, const float* gd, float dt, int B,
                                  int64_t n_complex, void* stream) {
-  FDBM_CHECK(x_new && x_mean && x && s && y && z && wx && ws && wy && gd, "fdbm_pc_predictor: null pointer");
-  FDBM_CHECK(dt <= 0.f, "fdbm_pc_predictor: dt must be <= 0 (reverse time), got %g", dt);
-  const int64_t nfloat = 2 * n_complex;
-  int gx = (int)((nfloat + 255) / 256);
-  if (gx > 2048) gx = 2048;
-  if (gx < 1) gx = 1;
-  pc_predictor_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(
-      (float*)x_new, (float*)x_mean, (const float*)x, (const float*)s, (const float*)y,
-      (const float*)z, wx, ws, wy, gd, dt, sqrtf(-dt), nfloat);
-  FDBM_LAUNCH_CHECK("fdbm_pc_predictor");
-  return 0;
+  return pc_predictor_impl(x_new, x_mean, x, s, y, z, nullptr, 0u, wx, ws, wy, gd, dt, B, n_complex, stream);
 }
 
+extern "C" int fdbm_pc_predictor_rng(void* x_new, void* x_mean, const void* x, const void* s, const void* y,
+                                     const uint32_t* rng, uint32_t draw, const float* wx, const float* ws,
+                                     const float* wy, const float* gd, float dt, int B, int64_t n_complex, void* stream) {
+  FDBM_CHECK(rng, "fdbm_pc_predictor_rng: null rng state");
+  return pc_predictor_impl(x_new, x_mean, x, s, y, nullptr, rng, draw, wx, ws, wy, gd, dt, B, n_complex, stream);
+}
+
+template <bool RNG>
 __global__ void __launch_bounds__(256) pc_corrector_kernel(
     float* __restrict__ xn, float* __restrict__ xm, const float* __restrict__ x,
-    const float* __restrict__ s, const float* __restrict__ y, const float* __restrict__ nz,
+    const float* __restrict__ s, const float* __restrict__ y, const float* __restrict__ nz, const uint32_t* __restrict__ rng, uint32_t draw,
     const float* a, const float* b, const float* den, const float* step, const float* nscale,
     int64_t nfloat) {
+  uint32_t s_lo = 0, s_hi = 0, dr = 0;
+  if constexpr (RNG) { s_lo = rng[0]; s_hi = rng[1]; dr = rng[2] + draw; }
   const int bi = blockIdx.y;
   const float fa = a[bi], fb = b[bi], fd = den[bi], fst = step[bi], fn = nscale[bi];
   const int64_t base = (int64_t)bi * nfloat;
@@ -197,25 +306,47 @@ __global__ void __launch_bounds__(256) pc_corrector_kernel(
     float score = __fdiv_rn(-__fsub_rn(xv, mean), fd);
     float m = __fadd_rn(xv, __fmul_rn(fst, score));
     xm[base + i] = m;
-    xn[base + i] = __fadd_rn(m, __fmul_rn(nz[base + i], fn));
+    float zv;
+    if constexpr (RNG) zv = rng_complex_normal((base + i) >> 1, dr, s_lo, s_hi)[i & 1]; else zv = nz[base + i];
+    xn[base + i] = __fadd_rn(m, __fmul_rn(zv, fn));
   }
+}
+
+static int pc_corrector_impl(void* x_new, void* x_mean, const void* x, const void* s,
+                             const void* y, const void* noise, const uint32_t* rng, uint32_t draw, const float* a, const float* b,
+                             const float* den, const float* step, const float* noise_scale,
+                             int B, int64_t n_complex, void* stream) {
+  FDBM_CHECK(x_new && x_mean && x && s && y && (noise || rng) && a && b && den && step && noise_scale,
+             "fdbm_pc_corrector: null pointer");
+  const int64_t nfloat = 2 * n_complex;
+  int gx = (int)((nfloat + 255) / 256);
+  if (gx > 2048) gx = 2048;
+  if (gx < 1) gx = 1;
+  if (rng)
+    pc_corrector_kernel<true><<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(
+        (float*)x_new, (float*)x_mean, (const float*)x, (const float*)s, (const float*)y,
+        nullptr, rng, draw, a, b, den, step, noise_scale, nfloat);
+  else
+    pc_corrector_kernel<false><<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(
+        (float*)x_new, (float*)x_mean, (const float*)x, (const float*)s, (const float*)y,
+        (const float*)noise, nullptr, 0u, a, b, den, step, noise_scale, nfloat);
+  FDBM_LAUNCH_CHECK("fdbm_pc_corrector");
+  return 0;
 }
 
 extern "C" int fdbm_pc_corrector(void* x_new, void* x_mean, const void* x, const void* s,
                                  const void* y, const void* noise, const float* a, const float* b,
                                  const float* den, const float* step, const float* noise_scale,
                                  int B, int64_t n_complex, void* stream) {
-  FDBM_CHECK(x_new && x_mean && x && s && y && noise && a && b && den && step && noise_scale,
-             "fdbm_pc_corrector: null pointer");
-  const int64_t nfloat = 2 * n_complex;
-  int gx = (int)((nfloat + 255) / 256);
-  if (gx > 2048) gx = 2048;
-  if (gx < 1) gx = 1;
-  pc_corrector_kernel<<<dim3(gx, B), 256, 0, (hipStream_t)stream>>>(
-      (float*)x_new, (float*)x_mean, (const float*)x, (const float*)s, (const float*)y,
-      (const float*)noise, a, b, den, step, noise_scale, nfloat);
-  FDBM_LAUNCH_CHECK("fdbm_pc_corrector");
-  return 0;
+  return pc_corrector_impl(x_new, x_mean, x, s, y, noise, nullptr, 0u, a, b, den, step, noise_scale, B, n_complex, stream);
+}
+
+extern "C" int fdbm_pc_corrector_rng(void* x_new, void* x_mean, const void* x, const void* s, const void* y,
+                                     const uint32_t* rng, uint32_t draw, const float* a, const float* b,
+                                     const float* den, const float* step, const float* noise_scale,
+                                     int B, int64_t n_complex, void* stream) {
+  FDBM_CHECK(rng, "fdbm_pc_corrector_rng: null rng state");
+  return pc_corrector_impl(x_new, x_mean, x, s, y, nullptr, rng, draw, a, b, den, step, noise_scale, B, n_complex, stream);
 }
 
 // Langevin corrector step size ON THE DEVICE (fdbm/util/correctors.py:46-51): grad_norm = mean_b ||score_b||,

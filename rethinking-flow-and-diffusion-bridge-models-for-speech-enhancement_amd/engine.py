@@ -17,8 +17,11 @@ from . import hip
 
 
 class SamplerGraph:
-    def __init__(self, net, bridge, kind, B, F, T):
+    def __init__(self, net, bridge, kind, B, F, T, in_kernel_noise=False):
         self.net, self.kind, self.N = net, kind, bridge.N
+        # sde with the library's counter-based generator: every step's noise is generated inside its step boundary
+        # (fdbm_step_boundary_rng, draw 1 + i); self.rng = the device words {seed_lo, seed_hi, draw_base} it reads
+        self.rng = None
         self.prog = net.program(B, F, T)
         dev = net.device
         table, t_model = bridge.ei_weight_table("ode" if kind == "ode" else "sde", B)
@@ -26,7 +29,10 @@ class SamplerGraph:
         # model time of each step as log t, evaluated on the host (see fdbm_temb)
         self.t_tab = torch.log(t_model[:, None] * torch.ones(1, B)).to(dev).contiguous()   # [N,B]
         self.z = None
-        if kind == "sde":
+        if kind == "sde" and in_kernel_noise:
+            from .bridge import rng_state
+            self.rng = rng_state(0, dev)
+        elif kind == "sde":
             self.z = torch.zeros(self.N, B, 1, F, T, dtype=torch.complex64, device=dev)
         self.graph = None
         self.key = self._bridge_key(bridge)
@@ -54,8 +60,12 @@ class SamplerGraph:
             upd = i_done is not None
             nxt = i_next is not None
             w = self.table[i_done] if upd else None
-            third = (prog.y_in if self.kind == "ode" else self.z[i_done]) if upd else None
-            hip.call("fdbm_step_boundary", p(prog.x_in), p(prog.y_in), p(third),
+            if upd and self.rng is not None:
+                name, third_args = "fdbm_step_boundary_rng", (p(self.rng), 1 + i_done)
+            else:
+                third = (prog.y_in if self.kind == "ode" else self.z[i_done]) if upd else None
+                name, third_args = "fdbm_step_boundary", (p(third),)
+            hip.call(name, p(prog.x_in), p(prog.y_in), *third_args,
                      ba["pyramid"] if upd else 0, ba["out_w"] if upd else 0, ba["out_b"] if upd else 0,
                      p(w[0]) if upd else 0, p(w[1]) if upd else 0, p(w[2]) if upd else 0,
                      ba["packed"] if nxt else 0, ba["arena"] if nxt else 0, ba["arena_bytes"] if nxt else 0,
@@ -67,6 +77,7 @@ class SamplerGraph:
             for i in range(self.N):
                 hip.call("fdbm_copy_f32", p(prog.dense_out), p(self.dense_tab[i * B]), B * R)
                 prog.run_body()
+                assert self.rng is None, "FDBM_STEP_BOUNDARY=0 (A/B) is built for injected noise"
                 third = prog.y_in if self.kind == "ode" else self.z[i]
                 w = self.table[i]
                 hip.call("fdbm_bridge_update", p(prog.x_in), p(prog.x_in), p(prog.s_out), p(third), p(w[0]), p(w[1]), p(w[2]), B, n)
@@ -89,12 +100,15 @@ class SamplerGraph:
             self._steps()
         self.graph = g
 
-    def run(self, y, x0, step_noise=None):
+    def run(self, y, x0, step_noise=None, seed=None):
         """y, x0: complex64 [B,1,F,T] device tensors; returns the final state (new tensor)."""
         prog = self.prog
         prog.y_in.copy_(y)
         prog.x_in.copy_(x0)
-        if self.kind == "sde":
+        if self.rng is not None:
+            from .bridge import rng_state
+            self.rng.copy_(rng_state(seed, "cpu"), non_blocking=True)       # 16 bytes: this call's seed; the draws are made in the graph
+        elif self.kind == "sde":
             for i in range(self.N):
                 self.z[i].copy_(step_noise())
         if self.graph is None:
@@ -113,9 +127,10 @@ class PcGraph:
     fdbm_langevin_step on the device.  Noise of all steps is drawn on the host in the reference's call order and
     uploaded before the replay."""
 
-    def __init__(self, net, bridge, B, F, T, predictor_name, corrector_name, snr, n_steps):
+    def __init__(self, net, bridge, B, F, T, predictor_name, corrector_name, snr, n_steps, in_kernel_noise=False):
         from .paths import ProbabilityPathSB  # noqa: F401  (sde_weights lives on the path)
         self.net, self.N, self.B = net, bridge.N, B
+        self.rng = None
         self.pred, self.corr, self.snr = predictor_name, corrector_name, float(snr)
         self.n_steps = n_steps if corrector_name != "none" else 0
         self.prog = net.program(B, F, T)
@@ -138,8 +153,17 @@ class PcGraph:
         self.dts = dts
         self.t_tab = torch.log(ts[:, None] * torch.ones(1, B)).to(dev).contiguous()
         z = lambda *lead: torch.zeros(*lead, B, 1, F, T, dtype=torch.complex64, device=dev)
-        self.zc = z(self.N, max(self.n_steps, 1))
-        self.zp = z(self.N)
+        if in_kernel_noise:
+            # the library's counter-based generator: draws numbered in the reference's call order (per grid point the
+            # corrector's, then the predictor's), each generated inside the move that consumes it; only the Langevin
+            # corrector, whose step size needs the draw's norm first, materialises its draw (one buffer, in the graph)
+            from .bridge import rng_state
+            self.rng = rng_state(0, dev)
+            self.zc = z(1, 1) if corrector_name == "langevin" else None
+            self.zp = None
+        else:
+            self.zc = z(self.N, max(self.n_steps, 1))
+            self.zp = z(self.N)
         self.x_new, self.x_mean = z(), z()
         self.lstep = torch.zeros(2, B, device=dev)
         self.lscratch = torch.zeros(B * 128, dtype=torch.float64, device=dev)
@@ -152,6 +176,7 @@ class PcGraph:
         p = hip.ptr
         R = self.net.dense_rows
         self.dense_tab = prog.dense_table(self.t_tab, self.dense_bufs)      # (as in SamplerGraph._steps)
+        draw = 1                       # (0 is the prior's)
         for i in range(self.N):
             # every evaluation at grid point i sees the same t: its Dense_0 rows go into place once
             hip.call("fdbm_copy_f32", p(prog.dense_out), p(self.dense_tab[i * B]), B * R)
@@ -159,18 +184,31 @@ class PcGraph:
                 prog.run_body()
                 c = self.ctab[i]
                 step, nscale = c[3], c[4]
+                zck = None if self.zc is None else (self.zc[0, 0] if self.rng is not None else self.zc[i, k])
                 if self.corr == "langevin":
+                    if self.rng is not None:
+                        hip.call("fdbm_randn_complex", p(zck), B * n, p(self.rng), draw)
                     hip.call("fdbm_langevin_step", p(self.lstep[0]), p(self.lstep[1]), p(self.lscratch), p(prog.x_in),
-                             p(prog.s_out), p(prog.y_in), p(self.zc[i, k]), p(c[0]), p(c[1]), p(c[2]), self.snr, B, n)
+                             p(prog.s_out), p(prog.y_in), p(zck), p(c[0]), p(c[1]), p(c[2]), self.snr, B, n)
                     step, nscale = self.lstep[0], self.lstep[1]
-                hip.call("fdbm_pc_corrector", p(self.x_new), p(self.x_mean), p(prog.x_in), p(prog.s_out), p(prog.y_in),
-                         p(self.zc[i, k]), p(c[0]), p(c[1]), p(c[2]), p(step), p(nscale), B, n)
+                if self.rng is not None and zck is None:
+                    hip.call("fdbm_pc_corrector_rng", p(self.x_new), p(self.x_mean), p(prog.x_in), p(prog.s_out), p(prog.y_in),
+                             p(self.rng), draw, p(c[0]), p(c[1]), p(c[2]), p(step), p(nscale), B, n)
+                else:
+                    hip.call("fdbm_pc_corrector", p(self.x_new), p(self.x_mean), p(prog.x_in), p(prog.s_out), p(prog.y_in),
+                             p(zck), p(c[0]), p(c[1]), p(c[2]), p(step), p(nscale), B, n)
+                draw += 1
                 hip.call("fdbm_copy_f32", p(prog.x_in), p(self.x_new), 2 * B * n)
             if self.pred == "euler_maruyama":
                 prog.run_body()
                 w = self.ptab[i]
-                hip.call("fdbm_pc_predictor", p(self.x_new), p(self.x_mean), p(prog.x_in), p(prog.s_out), p(prog.y_in),
-                         p(self.zp[i]), p(w[0]), p(w[1]), p(w[2]), p(w[3]), self.dts[i], B, n)
+                if self.rng is not None:
+                    hip.call("fdbm_pc_predictor_rng", p(self.x_new), p(self.x_mean), p(prog.x_in), p(prog.s_out), p(prog.y_in),
+                             p(self.rng), draw, p(w[0]), p(w[1]), p(w[2]), p(w[3]), self.dts[i], B, n)
+                else:
+                    hip.call("fdbm_pc_predictor", p(self.x_new), p(self.x_mean), p(prog.x_in), p(prog.s_out), p(prog.y_in),
+                             p(self.zp[i]), p(w[0]), p(w[1]), p(w[2]), p(w[3]), self.dts[i], B, n)
+                draw += 1
                 hip.call("fdbm_copy_f32", p(prog.x_in), p(self.x_new), 2 * B * n)
             else:
                 hip.call("fdbm_copy_f32", p(self.x_mean), p(prog.x_in), 2 * B * n)      # NonePredictor returns (x, x): x_mean = x
@@ -181,11 +219,15 @@ class PcGraph:
         prog = self.prog
         # the reference draws: per grid point the corrector's noise (after its model call), then the predictor's (before
         # its model call) - the generator only sees the ORDER of the draws
-        for i in range(self.N):
-            for k in range(self.n_steps):
-                self.zc[i, k].copy_(noise.step())
-            if self.pred == "euler_maruyama":
-                self.zp[i].copy_(noise.step())
+        if self.rng is not None:
+            from .bridge import rng_state
+            self.rng.copy_(rng_state(noise.device_seed, "cpu"), non_blocking=True)
+        else:
+            for i in range(self.N):
+                for k in range(self.n_steps):
+                    self.zc[i, k].copy_(noise.step())
+                if self.pred == "euler_maruyama":
+                    self.zp[i].copy_(noise.step())
         prog.y_in.copy_(y)
         prog.x_in.copy_(x0)
         if self.graph is None:
@@ -199,10 +241,11 @@ class PcGraph:
 def pc_with_graph(net, bridge, y, noise, predictor_name, corrector_name, snr, n_steps, denoise):
     """Fast path of Bridge.pc_sampler for this package's backbone and the registered predictors / correctors."""
     B, _, F, T = y.shape
-    key = ("pc", B, F, T, predictor_name, corrector_name, float(snr), int(n_steps), SamplerGraph._bridge_key(bridge))
+    key = ("pc", B, F, T, predictor_name, corrector_name, float(snr), int(n_steps), SamplerGraph._bridge_key(bridge), noise.in_kernel)
     pg = net._graphs.get(key)
     if pg is None:
-        pg = net._graphs[key] = PcGraph(net, bridge, B, F, T, predictor_name, corrector_name, snr, n_steps)
+        pg = net._graphs[key] = PcGraph(net, bridge, B, F, T, predictor_name, corrector_name, snr, n_steps,
+                                        in_kernel_noise=noise.in_kernel)
     with torch.no_grad():
         x0 = bridge.prior_sampling(y.contiguous(), noise)
         return pg.run(y.contiguous(), x0, noise, denoise)
@@ -211,10 +254,11 @@ def pc_with_graph(net, bridge, y, noise, predictor_name, corrector_name, snr, n_
 def sample_with_graph(net, bridge, y, kind, noise):
     """Fast path of Bridge.ode_sampler_ei / sde_sampler_ei for this package's backbone."""
     B, _, F, T = y.shape
-    key = (kind, B, F, T, SamplerGraph._bridge_key(bridge))
+    in_kernel = kind == "sde" and noise.in_kernel
+    key = (kind, B, F, T, SamplerGraph._bridge_key(bridge), in_kernel)
     sg = net._graphs.get(key)
     if sg is None:
-        sg = net._graphs[key] = SamplerGraph(net, bridge, kind, B, F, T)
+        sg = net._graphs[key] = SamplerGraph(net, bridge, kind, B, F, T, in_kernel_noise=in_kernel)
     with torch.no_grad():
         x0 = bridge.prior_sampling(y.contiguous(), noise)
-        return sg.run(y.contiguous(), x0, noise.step if kind == "sde" else None)
+        return sg.run(y.contiguous(), x0, noise.step if kind == "sde" else None, seed=noise.device_seed)

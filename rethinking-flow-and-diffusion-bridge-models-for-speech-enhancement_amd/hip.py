@@ -61,6 +61,10 @@ _SIGS = {
     "fdbm_pc_predictor": [c_void_p] * 10 + [c_float, c_int, c_i64],
     "fdbm_pc_corrector": [c_void_p] * 11 + [c_int, c_i64],
     "fdbm_langevin_step": [c_void_p] * 10 + [c_float, c_int, c_i64],
+    "fdbm_randn_complex": [c_void_p, c_i64, c_void_p, ctypes.c_uint32],
+    "fdbm_step_boundary_rng": [c_void_p] * 3 + [ctypes.c_uint32] + [c_void_p] * 7 + [c_void_p, c_i64, c_void_p, c_void_p, c_i64] + [c_int] * 4,
+    "fdbm_pc_predictor_rng": [c_void_p] * 6 + [ctypes.c_uint32] + [c_void_p] * 4 + [c_float, c_int, c_i64],
+    "fdbm_pc_corrector_rng": [c_void_p] * 6 + [ctypes.c_uint32] + [c_void_p] * 5 + [c_int, c_i64],
     "fdbm_pack_input": [c_void_p] * 3 + [c_int] * 4,
     "fdbm_unpack_output": [c_void_p] * 4 + [c_int] * 4,
     "fdbm_temb": [c_void_p] * 8 + [c_int] * 2,

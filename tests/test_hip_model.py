@@ -419,3 +419,41 @@ def test_pc_sampler_other_schedules_batch2(golden, sched):
     scale = max(1.0, ref.abs().max().item())
     assert (outs[0] - outs[1]).abs().max().item() < 2e-4 * scale, sched
     assert (outs[1] - ref).abs().max().item() < 5e-4 * scale, (sched, (outs[1] - ref).abs().max().item())
+
+
+def test_samplers_with_device_generated_noise(golden):
+    """device_seed: the stochastic samplers draw their noise with the library's counter-based generator ON the device
+    (draw 0 = prior, 1 + i = the i-th step draw), inside the kernel that consumes it when the sampler runs as a graph.
+    Graph == eager (which materialises the same draws with fdbm_randn_complex) bit for bit; the same seed reproduces,
+    another seed does not; the result equals injecting those draws by hand."""
+    g = golden("samplers")
+    y = T(g["y"]).to(DEV)
+    m = net("ncsnpp_v2_5M")
+    skw = dict(predictor_name="euler_maruyama", corrector_name="ald", corrector_steps=1, snr=0.5, denoise=False)
+    lkw = dict(skw, corrector_name="langevin")
+    for st, kw, n in (("sde_ei", {}, 4), ("pc", skw, 3), ("pc", lkw, 2)):
+        br = fdbm_amd.Bridge("sb", N=n, noise_schedule="bb", sampler_type=st)
+        a = br.sampler(m, y, device_seed=77, use_graph=True, **kw)
+        b = br.sampler(m, y, device_seed=77, use_graph=False, **kw)
+        assert torch.isfinite(torch.view_as_real(a)).all()
+        if kw.get("corrector_name") == "langevin":
+            # (eager takes the norms through torch reductions, the graph through fdbm_langevin_step: same draws, fp32-close)
+            assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item()), st
+        else:
+            assert torch.equal(torch.view_as_real(a), torch.view_as_real(b)), st
+        assert torch.equal(torch.view_as_real(a), torch.view_as_real(br.sampler(m, y, device_seed=77, **kw)))
+        assert not torch.equal(torch.view_as_real(a), torch.view_as_real(br.sampler(m, y, device_seed=78, **kw)))
+        # by hand: the draws as tensors
+        from fdbm_amd.bridge import rng_state
+        from fdbm_amd import hip
+        stw = rng_state(77, DEV)
+
+        def draw(i):
+            z = torch.empty_like(y)
+            hip.call("fdbm_randn_complex", hip.ptr(z), z.numel(), hip.ptr(stw), 1 + i)
+            return z
+        c = br.sampler(m, y, prior_noise=torch.zeros_like(y), step_noise=draw, **kw)
+        if kw.get("corrector_name") == "langevin":
+            assert (a - c).abs().max().item() <= 1e-4 * max(1.0, c.abs().max().item())
+        else:
+            assert torch.equal(torch.view_as_real(a), torch.view_as_real(c)), st

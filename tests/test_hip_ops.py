@@ -109,6 +109,77 @@ def test_step_boundary_equals_the_separate_launches():
         hip.call("fdbm_step_boundary", hip.ptr(x3), hip.ptr(y), 0, hip.ptr(pyr), 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, B, F, Fn, Tn)
 
 
+def _rng_words(seed, base=0):
+    from fdbm_amd.bridge import rng_state
+    return rng_state(seed, DEV, base)
+
+
+@pytest.mark.parametrize("seed,draw,base", [(0, 0, 0), (0x0123456789ABCDEF, 7, 0), (2 ** 63 + 5, 3, 40), (99, 0xFFFFFFF0, 9)])
+def test_device_rng_matches_numpy_restatement(seed, draw, base):
+    """fdbm_randn_complex (Philox4x32-10 keyed by (seed, draw, element) + Box-Muller, include/fdbm_hip.h) against
+    oracle/rng.py, which Random123's known-answer vectors pin (tests/test_host_api.py): the same uniforms bit for bit,
+    so the normals agree to the last bits of logf / sincosf (2e-6 ABSOLUTE at |z| <= 4.1), and N(0, 1/2) moments."""
+    from oracle import rng as orng
+    n = 70001
+    out = torch.empty(n, dtype=torch.complex64, device=DEV)
+    st = _rng_words(seed, base)
+    hip.call("fdbm_randn_complex", hip.ptr(out), n, hip.ptr(st), draw)
+    ref = torch.from_numpy(orng.complex_normal(n, (base + draw) & 0xFFFFFFFF, seed & 0xFFFFFFFFFFFFFFFF))
+    assert (out.cpu() - ref).abs().max().item() < 2e-6
+    z = torch.view_as_real(out.cpu())
+    assert abs(z.mean().item()) < 6e-3 and abs(z.var().item() - 0.5) < 6e-3 and abs((z[:, 0] * z[:, 1]).mean().item()) < 6e-3
+    # another draw / another seed: a different stream
+    out2 = torch.empty_like(out)
+    hip.call("fdbm_randn_complex", hip.ptr(out2), n, hip.ptr(st), (draw + 1) & 0xFFFFFFFF)
+    assert (out2 - out).abs().mean().item() > 0.5
+
+
+def test_device_rng_fused_forms_equal_the_materialised_draw():
+    """The *_rng forms of the sampler kernels generate their noise in registers: bit-identical to feeding the plain
+    forms the tensor fdbm_randn_complex writes for the same (seed, draw)."""
+    B, F, Tn, Fn = 2, 257, 64, 256
+    st = _rng_words(4242, 3)
+    draw = 5
+    z = torch.empty(B, 1, F, Tn, dtype=torch.complex64, device=DEV)
+    hip.call("fdbm_randn_complex", hip.ptr(z), z.numel(), hip.ptr(st), draw)
+    x, y, s = (crnd(B, 1, F, Tn, seed=i).to(DEV) for i in (1, 2, 3))
+    pyr = rnd(B, Fn, Tn, 4, seed=4).to(DEV).contiguous()
+    ow, ob = rnd(2, 4, seed=5).to(DEV).contiguous(), rnd(2, seed=6).to(DEV)
+    wa, wb, wc = (torch.tensor(v, device=DEV) for v in ([0.7, -2.5], [1.3, 0.25], [0.1, 3.0]))
+    xa, xb = x.clone(), x.clone()
+    ia, ib = (torch.empty(B, Fn, Tn, 4, device=DEV) for _ in range(2))
+    hip.call("fdbm_step_boundary", hip.ptr(xa), hip.ptr(y), hip.ptr(z), hip.ptr(pyr), hip.ptr(ow), hip.ptr(ob), hip.ptr(wa), hip.ptr(wb),
+             hip.ptr(wc), hip.ptr(ia), 0, 0, 0, 0, 0, B, F, Fn, Tn)
+    hip.call("fdbm_step_boundary_rng", hip.ptr(xb), hip.ptr(y), hip.ptr(st), draw, hip.ptr(pyr), hip.ptr(ow), hip.ptr(ob), hip.ptr(wa),
+             hip.ptr(wb), hip.ptr(wc), hip.ptr(ib), 0, 0, 0, 0, 0, B, F, Fn, Tn)
+    assert torch.equal(torch.view_as_real(xa), torch.view_as_real(xb)) and torch.equal(ia, ib)
+    n = F * Tn
+    w4 = [torch.tensor(v, device=DEV) for v in ([1.5, -0.3], [-2.0, 0.4], [0.7, 0.2], [1.0, 0.8])]
+    outs = []
+    for rng_form in (False, True):
+        xn, xm = torch.empty_like(x), torch.empty_like(x)
+        if rng_form:
+            hip.call("fdbm_pc_predictor_rng", hip.ptr(xn), hip.ptr(xm), hip.ptr(x), hip.ptr(s), hip.ptr(y), hip.ptr(st), draw,
+                     *[hip.ptr(w) for w in w4], -0.0312, B, n)
+        else:
+            hip.call("fdbm_pc_predictor", hip.ptr(xn), hip.ptr(xm), hip.ptr(x), hip.ptr(s), hip.ptr(y), hip.ptr(z),
+                     *[hip.ptr(w) for w in w4], -0.0312, B, n)
+        outs.append((xn, xm))
+    assert all(torch.equal(torch.view_as_real(a), torch.view_as_real(b)) for a, b in zip(*outs))
+    c5 = [torch.tensor(v, device=DEV) for v in ([0.3, 0.6], [0.7, 0.4], [0.2, 0.05], [0.01, 0.002], [0.1414, 0.0632])]
+    outs = []
+    for rng_form in (False, True):
+        xn, xm = torch.empty_like(x), torch.empty_like(x)
+        if rng_form:
+            hip.call("fdbm_pc_corrector_rng", hip.ptr(xn), hip.ptr(xm), hip.ptr(x), hip.ptr(s), hip.ptr(y), hip.ptr(st), draw,
+                     *[hip.ptr(w) for w in c5], B, n)
+        else:
+            hip.call("fdbm_pc_corrector", hip.ptr(xn), hip.ptr(xm), hip.ptr(x), hip.ptr(s), hip.ptr(y), hip.ptr(z),
+                     *[hip.ptr(w) for w in c5], B, n)
+        outs.append((xn, xm))
+    assert all(torch.equal(torch.view_as_real(a), torch.view_as_real(b)) for a, b in zip(*outs))
+
+
 def test_pc_moves():
     B = 2
     x, s, y, z = (crnd(B, 1, 257, 16, seed=i) for i in range(4))

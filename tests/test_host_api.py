@@ -373,3 +373,14 @@ def test_flac_in_the_folder_driver(tmp_path):
     assert sr == 16000 and y.shape == (1, 5000) and y.dtype == np.float32
     assert np.array_equal(y[0], (x / 32768.0).astype(np.float32))
     assert str(p) in infer.get_audio_files(str(tmp_path))
+
+
+def test_philox_restatement_known_answers():
+    """oracle/rng.py (the numpy restatement the device generator is tested against) reproduces Random123's published
+    known-answer vectors for philox4x32-10, and its normals have the stated distribution."""
+    from oracle import rng
+    for counter, key, out in rng.KAT:
+        assert tuple(int(v) for v in rng.philox4x32_10(*counter, *key)) == out
+    z = rng.complex_normal(200000, 1, 12345)
+    assert abs(z.real.mean()) < 5e-3 and abs(z.real.var() - 0.5) < 5e-3 and abs(z.imag.var() - 0.5) < 5e-3
+    assert np.array_equal(rng.complex_normal(16, 1, 12345, first=100), z[100:116])       # element-addressable

@@ -96,6 +96,20 @@ class HotPath:
         return x_hat, X
 
 
+class StubHotPath:
+    """FDBM_BENCH_STUB=1: a host-only stand-in for HotPath (x_hat = the input, X = a constant spectrogram per clip) so that
+    the multi-rank control flow - launcher, world-size assertion, sharding, gather rounds, barrier / max-over-ranks timing,
+    teardown order - is covered by a CPU test under gloo (tests/test_bench_ranks.py).  Never used for a measurement."""
+
+    def __init__(self, batch):
+        self.B = batch
+        self.net = None
+
+    def enhance(self, wave):
+        X = torch.full((wave.shape[0], 1, 257, 256), 1.0 + 0.5j, dtype=torch.complex64) * wave[:, :1, None, None].abs().max()
+        return wave, X
+
+
 def time_conv_launches(net, B, F, T, reps=3):
     """HIP-event time of every conv_igemm launch of one forward (eager, same stream)."""
     from fdbm_amd import hip
@@ -144,6 +158,39 @@ def time_conv_launches(net, B, F, T, reps=3):
         flops.append(2.0 * ca.B * ca.H * ca.W * ca.Cout * k)
     kinds = launched            # kernel family of each launch as the library reports it (fdbm_conv_last_kind)
     return best, flops, kinds, fwd_ms, prog
+
+
+def end_to_end_error_n30(dev, dtype16):
+    """The modes' error on the FINAL spectrogram after N = 30 (the quantity the north-star's 1e-4 is about): the contractive
+    fixture (tests/golden/contractive_ncsnpp_v2.npz - the reference's own N = 30 sb/bb result for this noisy spectrogram and
+    these weights) evaluated in the 16-bit throughput mode, in the f32 mode and in the split-precision mode.
+    Asserted in tests/test_hip_parity.py::test_modes_end_to_end_error_n30."""
+    import numpy as np
+    import fdbm_amd
+    from fdbm_amd.arch import Spec, VARIANTS
+    from fdbm_amd.backbone import HipNCSNpp
+    from fdbm_amd.weights import fill_state_dict
+    fix = os.path.join(ROOT, "tests", "golden", "contractive_ncsnpp_v2.npz")
+    if not os.path.exists(fix):
+        return {}
+    g = np.load(fix)
+    y = torch.from_numpy(g["y"]).to(dev)
+    ref = torch.from_numpy(g["sb_bb_ode_ei_N30"])
+    sd = {k: torch.from_numpy(np.asarray(v))
+          for k, v in fill_state_dict(Spec(**VARIANTS["ncsnpp_v2"]).param_shapes(), seed=0, profile="contractive").items()}
+    br = fdbm_amd.Bridge("sb", N=30, noise_schedule="bb", sampler_type="ode_ei")
+    if dtype16 not in (torch.bfloat16, torch.float16):
+        dtype16 = torch.bfloat16
+    tag16 = "bf16" if dtype16 == torch.bfloat16 else "f16"
+    xs = {}
+    for tag, kw in ((tag16, dict(dtype=dtype16)), ("f32", dict(dtype=torch.float32)), ("f32s", dict(dtype=torch.float32, split=True))):
+        m = HipNCSNpp(device=dev, state=sd, **VARIANTS["ncsnpp_v2"], **kw)
+        xs[tag] = br.sampler(m, y, generator=torch.Generator().manual_seed(4321)).cpu()
+        del m
+    out = {f"{tag}_final_max_abs_vs_reference_n30": float((x - ref).abs().max()) for tag, x in xs.items()}
+    out[f"{tag16}_final_max_abs_vs_f32_n30"] = float((xs[tag16] - xs["f32"]).abs().max())
+    out["final_spectrogram_max_abs"] = float(ref.abs().max())
+    return out
 
 
 def cpu_baseline(n_forwards, n_steps):
@@ -232,7 +279,10 @@ def main():
     # FDBM_BENCH_BACKEND=gloo: rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks
     # (ranks share devices, the gather goes through host memory); the real runs use RCCL
     backend = os.environ.get("FDBM_BENCH_BACKEND", "nccl")
-    if backend == "gloo":
+    stub = os.environ.get("FDBM_BENCH_STUB", "") == "1"        # host-only rehearsal of the rank control flow (CPU tests)
+    if stub and backend != "gloo":
+        raise SystemExit("bench.py: FDBM_BENCH_STUB=1 is a gloo rehearsal (set FDBM_BENCH_BACKEND=gloo); it measures nothing")
+    if backend == "gloo" and not stub:
         local_rank = local_rank % max(1, torch.cuda.device_count())
     comm_world = 1
     if world > 1:
@@ -244,14 +294,18 @@ def main():
             dist.init_process_group(backend)
         comm_world = dist.get_world_size()
         assert comm_world == args.gpus, (comm_world, args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device(f"cuda:{local_rank}")
+    sync = (lambda: None) if stub else torch.cuda.synchronize
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32s": torch.float32}[args.dtype]
     split = args.dtype == "f32s"
     evals_per_step = 2 * args.N if args.sampler == "pc" else args.N        # pc: predictor + 1 corrector evaluation
 
     from fdbm_amd import dist as fdist
-    hp = HotPath(dev, dtype, args.N, args.batch, backbone=args.backbone, sampler=args.sampler, split=split)
+    hp = StubHotPath(args.batch) if stub else HotPath(dev, dtype, args.N, args.batch, backbone=args.backbone, sampler=args.sampler, split=split)
     if args.clips:
         # configs[3]: the list is sharded by index (rank r takes clips r, r + W, ...: fdbm_amd.dist.shard_indices), every
         # rank walks its shard in batches of --batch (a ragged last batch is padded with its first clip and trimmed)
@@ -269,10 +323,13 @@ def main():
     else:
         batches = [(synth_clips(args.batch, 1000 + rank, dev), args.batch)]   # resident in HBM before timing
         rounds = 1
-    wave = batches[0][0]
+    wave = batches[0][0] if batches else None
+
+    gather_stats = {"bytes": 0, "seconds": 0.0, "calls": 0}
 
     def step():
-        x_hat = None
+        x_hat = torch.zeros(0, device=dev)
+        X = torch.zeros(0, 1, 257, 256, dtype=torch.complex64, device=dev)     # (a rank whose shard is empty sends empty batches)
         for r in range(rounds):
             if r < len(batches):
                 w, real = batches[r]
@@ -286,7 +343,13 @@ def main():
                       f"x_hat finite {bool(torch.isfinite(x_hat).all())}", file=sys.stderr, flush=True)
             if world > 1:
                 # enhanced spectrograms only, to rank 0, over RCCL / xGMI (gloo rehearsal: through host memory)
+                sync()
+                tg = time.perf_counter()
                 fdist.gather_spectrograms(X if backend == "nccl" else X.cpu(), dst=0)
+                sync()
+                gather_stats["seconds"] += time.perf_counter() - tg
+                gather_stats["bytes"] += X.numel() * 8
+                gather_stats["calls"] += 1
         return x_hat
 
     def barrier():
@@ -296,17 +359,29 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize(); barrier()
+    gather_stats.update(bytes=0, seconds=0.0, calls=0)
+    sync(); barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    torch.cuda.synchronize(); barrier()
+    sync()
+    own_elapsed = time.perf_counter() - t0          # this rank's own work, before it waits for the others
+    barrier()
     elapsed = time.perf_counter() - t0
+    per_rank = None
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        cdev = dev if backend == "nccl" else "cpu"
+        tt = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+        # self-diagnosis for the scaling curve: every rank's own time, gather time and gathered bytes (rank 0 reports them)
+        mine = torch.tensor([own_elapsed, gather_stats["seconds"], float(gather_stats["bytes"]), float(gather_stats["calls"])],
+                            device=cdev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(rank=r, elapsed_s=float(v[0]), gather_s=float(v[1]), gather_bytes_sent=int(v[2]), gather_calls=int(v[3]))
+                    for r, v in enumerate(allr)]
     assert torch.isfinite(out).all(), f"rank {rank}: {int((~torch.isfinite(out)).sum())} non-finite samples of {out.numel()}"
 
     n_clips_step = args.clips if args.clips else world * args.batch
@@ -319,6 +394,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank != 0:
+        return
+    if stub:
+        print(json.dumps({"metric": "stub (FDBM_BENCH_STUB=1: rank control flow only, nothing measured)", "value": None, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "rccl_world_size": comm_world, "backend": backend,
+                          "clips_per_step": n_clips_step, "per_rank": per_rank}))
         return
 
     F, T = 257, 256
@@ -339,6 +419,8 @@ def main():
                    "parallelism": f"dp{world} (utterance sharding, gather of spectrograms)"},
         "whole_step_tflops": n_clips_step * evals_per_step * flops_fwd / (elapsed / args.steps) / 1e12,
     }
+    if per_rank is not None:
+        result["per_rank"] = per_rank          # own time / gather time / gathered bytes of every rank over the timed steps
 
     # ---- roofline of the dominant kernel ---------------------------------------------------
     # conv_patch_kernel (3x3 convs of the large feature maps) carries most of the algorithmic
@@ -346,7 +428,9 @@ def main():
     # all_conv = the same over every convolution launch (both kernels), i.e. incl. the
     # latency-bound small-map layers.
     times, flops, kinds, fwd_ms, prog = time_conv_launches(hp.net, args.batch, F, T)
-    peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_DENSE_PEAK_TFLOPS       # f16 = bf16 dense MFMA peak
+    # f16 = the bf16 dense MFMA peak; f32s computes every product as three f16 MFMAs: its ALGORITHMIC flops are priced against
+    # a third of that peak (833 TFLOP/s effective)
+    peak = F32_MFMA_PEAK_TFLOPS if args.dtype == "f32" else BF16_DENSE_PEAK_TFLOPS / 3 if args.dtype == "f32s" else BF16_DENSE_PEAK_TFLOPS
     dom = 3 if any(k == 3 for k in kinds) else 1
     sel = [i for i, k in enumerate(kinds) if k == dom] or list(range(len(times)))
     t_dom = sum(times[i] for i in sel) * 1e-3
@@ -355,12 +439,16 @@ def main():
     traffic = None
     fam_name = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel", 3: "conv_ring_kernel<R=16>",
                 4: "conv_ring_kernel<R=8>", 5: "conv_head_kernel"}
-    pmc = os.path.join(ROOT, "profiles", "r02", f"pmc_traffic_b{args.batch}_bf16.json")
-    if args.dtype == "bf16" and os.path.exists(pmc):
-        try:        # measured offline with rocprofv3 --pmc (tools/pmc_workload.py), bytes per launch
-            traffic = json.load(open(pmc))[fam_name[dom]]["hbm_bytes_per_launch_corrected"]
-        except Exception:
-            traffic = None
+    pmc_tab, pmc_src = {}, None
+    for rnd in ("r03", "r02"):          # the newest committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command)
+        cand = os.path.join(ROOT, "profiles", rnd, f"pmc_traffic_b{args.batch}_bf16.json")
+        if args.dtype == "bf16" and os.path.exists(cand):
+            try:
+                pmc_tab, pmc_src = json.load(open(cand)), f"profiles/{rnd}/pmc_traffic_b{args.batch}_bf16.json (offline rocprofv3 --pmc pass, not measured by this run)"
+                break
+            except Exception:
+                pmc_tab, pmc_src = {}, None
+    traffic = pmc_tab.get(fam_name[dom], {}).get("hbm_bytes_per_launch_corrected")
     t_conv = sum(times) * 1e-3
     families = {}
     for kind, name in fam_name.items():
@@ -369,10 +457,21 @@ def main():
             tt, ff = sum(times[i] for i in ids) * 1e-3, sum(flops[i] for i in ids)
             families[name] = {"launches_per_forward": len(ids), "ms_per_forward": 1e3 * tt,
                               "achieved": ff / tt / 1e12, "frac": ff / tt / 1e12 / peak,
-                              "share_of_forward_flops": ff / sum(flops), "share_of_conv_time": tt / t_conv}
+                              "share_of_forward_flops": ff / sum(flops), "share_of_conv_time": tt / t_conv,
+                              "traffic_over_algorithmic": pmc_tab.get(name, {}).get("traffic_over_algorithmic")}
+    # what bounds the timed workload: the family with the largest share of the convolution TIME (at batch 1 that is not the
+    # family with the most flops)
+    bt_name = max(families, key=lambda k: families[k]["share_of_conv_time"])
+    bt = families[bt_name]
     result["roofline"] = {
         "bound": "mfma", "kernel": fam_name[dom] if any(k == dom for k in kinds) else "conv_igemm_kernel",
         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
+        "traffic_source": pmc_src,
+        "selected_by": "share of the forward's algorithmic flops",
+        "by_time": {"kernel": bt_name, "selected_by": "share of the forward's convolution time", "share_of_conv_time": bt["share_of_conv_time"],
+                    "achieved": bt["achieved"], "frac": bt["frac"], "ms_per_forward": bt["ms_per_forward"],
+                    "launches_per_forward": bt["launches_per_forward"], "traffic_over_algorithmic": bt["traffic_over_algorithmic"],
+                    "traffic_source": pmc_src},
         "launches_per_forward": len(sel), "avg_launch_us": 1e6 * t_dom / len(sel),
         "algorithmic_gflop_per_launch_avg": f_dom / len(sel) / 1e9,
         "share_of_forward_flops": f_dom / sum(flops),
@@ -393,6 +492,19 @@ def main():
             t1 = time.perf_counter(); hp32.enhance(w1); hp32.enhance(w1); torch.cuda.synchronize()
             extras["fp32_parity_mode_rtf_b1"] = 2 * CLIP_SECONDS / (time.perf_counter() - t1)
             del hp32
+            if args.dtype != "f32s":
+                # the parity mode that runs on the 16-bit matrix pipe (f32 tensors, three f16 MFMAs per product): its own bench
+                # line is `--dtype f32s`; here 5 timed clips beside the headline
+                hps = HotPath(dev, torch.float32, args.N, 1, backbone=args.backbone, split=True)
+                hps.enhance(w1); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    hps.enhance(w1)
+                torch.cuda.synchronize()
+                extras["f32s_parity_mode_rtf_b1"] = 5 * CLIP_SECONDS / (time.perf_counter() - t1)
+                del hps
+            if args.backbone == "ncsnpp_v2":
+                extras.update(end_to_end_error_n30(dev, dtype if args.dtype != "f32s" else torch.bfloat16))
             if args.batch == 1 and not args.clips:
                 hp64 = HotPath(dev, dtype, args.N, 64, backbone=args.backbone)
                 w64 = synth_clips(64, 77, dev)

@@ -101,6 +101,20 @@ int fdbm_pc_corrector_rng(void* x_new, void* x_mean, const void* x, const void* 
                           const uint32_t* rng, uint32_t draw, const float* a, const float* b, const float* den,
                           const float* step, const float* noise_scale, int B, int64_t n_complex, void* stream);
 
+/* ------------------------------------------------------------------ ode_sampler_int on the device
+ * The stage arithmetic of one Dormand-Prince RK45 step of `ode_sampler_int` (fdbm/bridge.py:115-140, which calls
+ * scipy.integrate.solve_ivp(method="RK45") on the host: scipy/integrate/_ivp/rk.py rk_step / _step_impl) over the
+ * complex128 state [n_complex], resident on the device (fdbm_amd/odeint.py drives the step-size control):
+ *   fdbm_rk45_lincomb  out = y + scale * (c_0 K_0 + c_1 K_1 + ... + c_{nk-1} K_{nk-1}), terms added in index order, zero
+ *                      coefficients skipped (their K_j may be NULL): the stage inputs and y_new.  K: HOST array of nk
+ *                      device pointers, coef: HOST array of nk doubles (nk <= 7).  out may alias nothing it reads.
+ *   fdbm_rk45_error    partial[0..255] = per-block sums of |(sum_j e_j K_j) h / (atol + rtol max(|y|, |y_new|))|^2; the error
+ *                      norm of the step is sqrt(sum(partial) / n_complex).  K, e: HOST arrays of 7. */
+int fdbm_rk45_lincomb(void* out, const void* y, const void* const* K, const double* coef, int nk, double scale,
+                      int64_t n_complex, void* stream);
+int fdbm_rk45_error(double* partial /*device [256]*/, const void* const* K, const double* e, const void* y, const void* y_new,
+                    double h, double atol, double rtol, int64_t n_complex, void* stream);
+
 /* ------------------------------------------------------------------ network input / output
  * cat(x.re, x.im, y.re, y.im) with the Nyquist row dropped when F == 257
  * (fdbm/backbones/ncsnpp_v2.py:247-250): complex64 [B][1][F][T] x2 -> f32 [B][Fn][T][4]. */
@@ -116,9 +130,11 @@ int fdbm_unpack_output(void* out, const float* pyr, const float* w, const float*
  * GaussianFourierProjection(log t) -> Linear -> SiLU -> Linear, then SiLU again (every
  * consumer applies act(temb) first): out f32 [B][4nf] = silu(temb).  The Fourier argument
  * is formed as ((log t * W) * 2) * pi in fp32 (layerspp.py:40; ncsnpp_v2.py:252-270).
- * log_t is log(t) evaluated by the HOST (fp32): arguments reach thousands of radians, so a
- * 1-ulp difference between two libms' logf moves sin/cos by up to 1e-4 (hard
- * part 7); with the host's log the argument is bit-identical to the reference's. */
+ * log_t is log(t) evaluated by the HOST: arguments reach thousands of radians, so a 1-ulp
+ * difference between two logf moves sin/cos by up to 1e-4 (hard part 7).  Give the
+ * CORRECTLY ROUNDED float32 logarithm (evaluate in float64, round once - fdbm_amd.hip.log_time):
+ * a float32 logf may be one unit off near a rounding tie and two hosts' vector libms disagree
+ * there (observed at t = 0.10009 of the 30-step grids, 0.4988 ulp from the tie). */
 int fdbm_temb(float* out_act, const float* log_t, const float* fourier_w, const float* w1,
               const float* b1, const float* w2, const float* b2, float* scratch, int B, int nf,
               void* stream);
@@ -465,6 +481,12 @@ void fdbm_tfgridnet_destroy(fdbm_tfgridnet_ctx* ctx);
  * block_out (may be NULL): f32 [n_layers][B][T][F][C], every block's output (parity tests). */
 int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* ctx, const void* x, const void* y, const float* log_t, void* out,
                            int B, int F, int T, void* workspace, int64_t workspace_bytes, float* block_out, void* stream);
+/* The same evaluation entered at block `first_block` (1 .. n_layers - 1) with block_in f32 [B][T][F][C] as that block's
+ * input (= the previous GridNetV3Block's output, tfgridnet.py:224-225); the stem is skipped, everything behind runs as in
+ * fdbm_tfgridnet_forward (block_out rows < first_block are left untouched).  For teacher-forced per-block parity tests:
+ * recurrent blocks amplify fp32 rounding, so a free-running comparison only bounds the first block tightly. */
+int fdbm_tfgridnet_forward_from(fdbm_tfgridnet_ctx* ctx, const float* block_in, int first_block, const float* log_t, void* out,
+                                int B, int F, int T, void* workspace, int64_t workspace_bytes, float* block_out, void* stream);
 
 #ifdef __cplusplus
 }

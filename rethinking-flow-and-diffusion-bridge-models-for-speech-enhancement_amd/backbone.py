@@ -226,7 +226,7 @@ class HipNCSNpp:
         B, _, F, T = x.shape
         prog = self.program(B, F, T)
         # log t on the host: see fdbm_temb in include/fdbm_hip.h
-        log_t = torch.log(t.detach().to(device="cpu", dtype=torch.float32).reshape(B)).to(self.device)
+        log_t = hip.log_time(t).reshape(B).to(self.device)
         out = torch.empty_like(prog.s_out)
         prog.forward_into(x.to(torch.complex64).contiguous(), y.to(torch.complex64).contiguous(), log_t, out)
         return out

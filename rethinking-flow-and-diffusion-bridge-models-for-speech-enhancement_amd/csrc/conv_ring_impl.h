@@ -26,6 +26,12 @@
 
 #include "conv_common.h"
 
+// cache policy of the epilogue's output stores (raw buffer store `aux`: 0 = default write-back, 2 = nt, 16 = sc1
+// write-through).  Experiments: tools/build_store_variants.sh.
+#ifndef FDBM_RING_STORE_AUX
+#define FDBM_RING_STORE_AUX 0
+#endif
+
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 // Tile geometry: R image rows x 16 pixels x 128 output channels per workgroup.  R = 16 is the throughput shape (one
@@ -741,7 +747,7 @@ __global__ void __launch_bounds__(512) conv_ring_kernel(const ConvParams p, int 
           const auto y0_ = __builtin_amdgcn_permlane16_swap(pk[0].x, pk[1].x, false, false);
           const auto y1_ = __builtin_amdgcn_permlane16_swap(pk[0].y, pk[1].y, false, false);
           if (q == 0 ? okq0 : okq1)
-            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{y0_[0], y1_[0], y0_[1], y1_[1]}, ro, voff + q * 64, ii * rowB, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{y0_[0], y1_[0], y0_[1], y1_[1]}, ro, voff + q * 64, ii * rowB, FDBM_RING_STORE_AUX);
         }
       }
     }

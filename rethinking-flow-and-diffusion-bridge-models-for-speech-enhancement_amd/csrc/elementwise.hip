@@ -416,6 +416,103 @@ extern "C" int fdbm_langevin_step(float* step, float* noise_scale, void* scratch
 }
 
 // ---------------------------------------------------------------------------------
+// ode_sampler_int on the device (fdbm/bridge.py:115-140 -> scipy.integrate.solve_ivp(RK45); restated in
+// fdbm_amd/odeint.py): the stage arithmetic of one Dormand-Prince step over the complex128 state, one pass each
+// instead of ~25 stock elementwise launches per step.
+//   fdbm_rk45_lincomb   out = y + scale * (c_0 K_0 + c_1 K_1 + ...)   (terms added in index order; zero coefficients skipped)
+//                       - the stage inputs y + h sum_j a_sj K_j (c_j = a_sj h, scale = 1) and y_new = y + h sum_j b_j K_j
+//   fdbm_rk45_error     err = sum_j e_j K_j;  partial[blk] = sum over the block's elements of |err h / (atol + rtol max(|y|, |y_new|))|^2
+//                       (SciPy's error norm is sqrt(sum(partial) / n); 256 partials, summed by the caller in index order)
+// ---------------------------------------------------------------------------------
+struct Rk45Args {
+  const double2* K[7];
+  double c[7];
+  int nk;
+};
+
+__global__ void __launch_bounds__(256) rk45_lincomb_kernel(double2* __restrict__ out, const double2* __restrict__ y, const Rk45Args a,
+                                                           double scale, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double re = 0.0, im = 0.0;
+    bool first = true;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      if (j < a.nk && a.c[j] != 0.0) {
+        const double2 k = a.K[j][i];
+        if (first) { re = k.x * a.c[j]; im = k.y * a.c[j]; first = false; }
+        else { re = __dadd_rn(re, __dmul_rn(k.x, a.c[j])); im = __dadd_rn(im, __dmul_rn(k.y, a.c[j])); }
+      }
+    }
+    const double2 yv = y[i];
+    out[i] = double2{__dadd_rn(yv.x, __dmul_rn(scale, re)), __dadd_rn(yv.y, __dmul_rn(scale, im))};
+  }
+}
+
+extern "C" int fdbm_rk45_lincomb(void* out, const void* y, const void* const* K, const double* coef, int nk, double scale,
+                                 int64_t n_complex, void* stream) {
+  FDBM_CHECK(out && y && K && coef && nk >= 1 && nk <= 7 && n_complex > 0, "fdbm_rk45_lincomb: bad arguments (nk=%d)", nk);
+  Rk45Args a;
+  memset(&a, 0, sizeof(a));
+  a.nk = nk;
+  for (int j = 0; j < nk; ++j) {
+    FDBM_CHECK(K[j] || coef[j] == 0.0, "fdbm_rk45_lincomb: stage %d is NULL with a non-zero coefficient", j);
+    a.K[j] = (const double2*)K[j];
+    a.c[j] = K[j] ? coef[j] : 0.0;
+  }
+  int g = (int)((n_complex + 255) / 256);
+  if (g > 2048) g = 2048;
+  rk45_lincomb_kernel<<<g, 256, 0, (hipStream_t)stream>>>((double2*)out, (const double2*)y, a, scale, n_complex);
+  FDBM_LAUNCH_CHECK("fdbm_rk45_lincomb");
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) rk45_error_kernel(double* __restrict__ partial, const Rk45Args a, const double2* __restrict__ y,
+                                                         const double2* __restrict__ yn, double h, double atol, double rtol, int64_t n) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    double re = 0.0, im = 0.0;
+    bool first = true;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      if (a.c[j] != 0.0) {
+        const double2 k = a.K[j][i];
+        if (first) { re = k.x * a.c[j]; im = k.y * a.c[j]; first = false; }
+        else { re = __dadd_rn(re, __dmul_rn(k.x, a.c[j])); im = __dadd_rn(im, __dmul_rn(k.y, a.c[j])); }
+      }
+    }
+    const double2 a0 = y[i], a1 = yn[i];
+    const double m0 = sqrt(a0.x * a0.x + a0.y * a0.y), m1 = sqrt(a1.x * a1.x + a1.y * a1.y);
+    const double sc = atol + (m0 > m1 ? m0 : m1) * rtol;
+    const double er = re * h / sc, ei = im * h / sc;
+    acc += er * er + ei * ei;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+extern "C" int fdbm_rk45_error(double* partial, const void* const* K, const double* e, const void* y, const void* y_new, double h,
+                               double atol, double rtol, int64_t n_complex, void* stream) {
+  FDBM_CHECK(partial && K && e && y && y_new && n_complex > 0, "fdbm_rk45_error: bad arguments");
+  Rk45Args a;
+  memset(&a, 0, sizeof(a));
+  a.nk = 7;
+  for (int j = 0; j < 7; ++j) {
+    FDBM_CHECK(K[j] || e[j] == 0.0, "fdbm_rk45_error: stage %d is NULL with a non-zero coefficient", j);
+    a.K[j] = (const double2*)K[j];
+    a.c[j] = K[j] ? e[j] : 0.0;
+  }
+  rk45_error_kernel<<<256, 256, 0, (hipStream_t)stream>>>(partial, a, (const double2*)y, (const double2*)y_new, h, atol, rtol, n_complex);
+  FDBM_LAUNCH_CHECK("fdbm_rk45_error");
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------
 // network input / output
 // ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) pack_input_kernel(f32x4* __restrict__ out,

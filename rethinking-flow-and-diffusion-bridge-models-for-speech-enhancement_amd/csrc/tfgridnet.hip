@@ -562,10 +562,15 @@ static int tfg_gemm_launch(hipStream_t st, float* out, const float* A, const flo
 // x, y complex64 [B][1][F][T], log_t f32 [B] (host-evaluated logarithm of the model time), out complex64 [B][1][F][T];
 // workspace: fdbm_tfgridnet_workspace_bytes(d, B, F, T) bytes, contents irrelevant on entry.  block_out (optional, may be
 // NULL): f32 [n_layers][B][T][F][C], every block's output (tests).
-extern "C" int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* c, const void* x, const void* y, const float* log_t, void* out,
-                                      int B, int F, int T, void* workspace, int64_t workspace_bytes, float* block_out, void* stream) {
-  FDBM_CHECK(c && x && y && log_t && out && workspace, "fdbm_tfgridnet_forward: null argument");
+// block_in / first_block (fdbm_tfgridnet_forward_from): the evaluation starts at block `first_block` with block_in
+// [B][T][F][C] as that block's input (= the previous block's output); the stem is skipped.
+static int tfg_forward_impl(fdbm_tfgridnet_ctx* c, const void* x, const void* y, const float* log_t, void* out,
+                            int B, int F, int T, void* workspace, int64_t workspace_bytes, float* block_out,
+                            const float* block_in, int first_block, void* stream) {
+  FDBM_CHECK(c && log_t && out && workspace && (block_in || (x && y)), "fdbm_tfgridnet_forward: null argument");
   FDBM_CHECK(B >= 1 && F >= 1 && T >= 1 && T <= 4096, "fdbm_tfgridnet_forward: bad shape");
+  FDBM_CHECK((block_in == nullptr) == (first_block == 0) && first_block >= 0 && first_block < c->d.n_layers,
+             "fdbm_tfgridnet_forward_from: first_block %d needs its input (blocks 1 .. n_layers - 1), block 0 starts from x, y", first_block);
   const fdbm_tfgridnet_desc& d = c->d;
   const TfgWs ws = tfg_ws(d, B, F, T);
   FDBM_CHECK(workspace_bytes >= ws.total * 4, "fdbm_tfgridnet_forward: workspace too small (%lld < %lld bytes)",
@@ -585,12 +590,16 @@ extern "C" int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* c, const void* x, cons
   FDBM_CHECK(fdbm_memset_zero(stats, (int64_t)16 * B, st) == 0, "fdbm_tfgridnet_forward: memset failed");
   tfg_temb<<<B, 256, (size_t)10 * C * sizeof(float), st>>>(tb, log_t, wt + c->fourier, wt + c->t1w, wt + c->t1b, wt + c->t2w, wt + c->t2b,
                                                            wt + c->tlw, wt + c->tlb, B, C, d.n_layers);
-  tfg_pack_in<<<grid_for(px), 256, 0, st>>>(xin, (const float2*)x, (const float2*)y, B, F, T);
-  tfg_conv3x3<<<grid_for(px * C), 256, 0, st>>>(cur, xin, wt + c->conv_w, wt + c->conv_b, B, T, Q, d.in_ch, C);
-  tfg_sum_stats<<<dim3(64, B), 256, 0, st>>>(stats, cur, (int64_t)T * Q * C);
+  if (block_in) {
+    FDBM_CHECK(fdbm_copy_f32(cur, block_in, px * C, st) == 0, "fdbm_tfgridnet_forward_from: copy failed");
+  } else {
+    tfg_pack_in<<<grid_for(px), 256, 0, st>>>(xin, (const float2*)x, (const float2*)y, B, F, T);
+    tfg_conv3x3<<<grid_for(px * C), 256, 0, st>>>(cur, xin, wt + c->conv_w, wt + c->conv_b, B, T, Q, d.in_ch, C);
+    tfg_sum_stats<<<dim3(64, B), 256, 0, st>>>(stats, cur, (int64_t)T * Q * C);
+  }
   FDBM_LAUNCH_CHECK("fdbm_tfgridnet_forward(stem)");
 
-  for (int l = 0; l < d.n_layers; ++l) {
+  for (int l = first_block; l < d.n_layers; ++l) {
     const auto& b = c->blk[l];
     // x + time embedding (the stem's GroupNorm applied on the way in the first block), zero-padded by ks - 1
     tfg_gn_temb_pad<<<grid_for(pxp * C), 256, 0, st>>>(xp, cur, tb + (int64_t)l * B * C, l == 0 ? stats : nullptr, wt + c->gn_g,
@@ -664,4 +673,16 @@ extern "C" int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* c, const void* x, cons
   tfg_unpack_out<<<grid_for(px), 256, 0, st>>>((float2*)out, xin, B, F, T);
   FDBM_LAUNCH_CHECK("fdbm_tfgridnet_forward(head)");
   return 0;
+}
+
+extern "C" int fdbm_tfgridnet_forward(fdbm_tfgridnet_ctx* c, const void* x, const void* y, const float* log_t, void* out,
+                                      int B, int F, int T, void* workspace, int64_t workspace_bytes, float* block_out, void* stream) {
+  FDBM_CHECK(x && y, "fdbm_tfgridnet_forward: null argument");
+  return tfg_forward_impl(c, x, y, log_t, out, B, F, T, workspace, workspace_bytes, block_out, nullptr, 0, stream);
+}
+
+extern "C" int fdbm_tfgridnet_forward_from(fdbm_tfgridnet_ctx* c, const float* block_in, int first_block, const float* log_t, void* out,
+                                           int B, int F, int T, void* workspace, int64_t workspace_bytes, float* block_out, void* stream) {
+  FDBM_CHECK(block_in, "fdbm_tfgridnet_forward_from: null block input");
+  return tfg_forward_impl(c, nullptr, nullptr, log_t, out, B, F, T, workspace, workspace_bytes, block_out, block_in, first_block, stream);
 }

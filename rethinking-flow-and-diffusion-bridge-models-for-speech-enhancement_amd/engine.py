@@ -27,7 +27,7 @@ class SamplerGraph:
         table, t_model = bridge.ei_weight_table("ode" if kind == "ode" else "sde", B)
         self.table = table.to(dev).contiguous()                       # [N,3,B]
         # model time of each step as log t, evaluated on the host (see fdbm_temb)
-        self.t_tab = torch.log(t_model[:, None] * torch.ones(1, B)).to(dev).contiguous()   # [N,B]
+        self.t_tab = hip.log_time(t_model[:, None] * torch.ones(1, B)).to(dev).contiguous()   # [N,B]
         self.z = None
         if kind == "sde" and in_kernel_noise:
             from .bridge import rng_state
@@ -151,7 +151,7 @@ class PcGraph:
         self.ctab = torch.stack(ctab).to(dev).contiguous()         # [N,5,B]
         self.ptab = torch.stack(ptab).to(dev).contiguous()         # [N,4,B]
         self.dts = dts
-        self.t_tab = torch.log(ts[:, None] * torch.ones(1, B)).to(dev).contiguous()
+        self.t_tab = hip.log_time(ts[:, None] * torch.ones(1, B)).to(dev).contiguous()
         z = lambda *lead: torch.zeros(*lead, B, 1, F, T, dtype=torch.complex64, device=dev)
         if in_kernel_noise:
             # the library's counter-based generator: draws numbered in the reference's call order (per grid point the

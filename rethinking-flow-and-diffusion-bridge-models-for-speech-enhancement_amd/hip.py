@@ -65,6 +65,8 @@ _SIGS = {
     "fdbm_step_boundary_rng": [c_void_p] * 3 + [ctypes.c_uint32] + [c_void_p] * 7 + [c_void_p, c_i64, c_void_p, c_void_p, c_i64] + [c_int] * 4,
     "fdbm_pc_predictor_rng": [c_void_p] * 6 + [ctypes.c_uint32] + [c_void_p] * 4 + [c_float, c_int, c_i64],
     "fdbm_pc_corrector_rng": [c_void_p] * 6 + [ctypes.c_uint32] + [c_void_p] * 5 + [c_int, c_i64],
+    "fdbm_rk45_lincomb": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_double, c_i64],
+    "fdbm_rk45_error": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double, c_i64],
     "fdbm_pack_input": [c_void_p] * 3 + [c_int] * 4,
     "fdbm_unpack_output": [c_void_p] * 4 + [c_int] * 4,
     "fdbm_temb": [c_void_p] * 8 + [c_int] * 2,
@@ -97,7 +99,7 @@ EXPORTS = sorted(list(_SIGS) + ["fdbm_last_error", "fdbm_version", "fdbm_conv_kc
                                 "fdbm_ncsnpp_forward", "fdbm_program_workspace_bytes", "fdbm_program_weights_bytes",
                                 "fdbm_ncsnpp_create_from_program", "fdbm_tfgridnet_weights_count",
                                 "fdbm_tfgridnet_workspace_bytes", "fdbm_tfgridnet_create", "fdbm_tfgridnet_destroy",
-                                "fdbm_tfgridnet_forward"])
+                                "fdbm_tfgridnet_forward", "fdbm_tfgridnet_forward_from"])
 
 
 def lib():
@@ -151,6 +153,9 @@ def lib():
         L.fdbm_tfgridnet_forward.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                              c_void_p, c_i64, c_void_p, c_void_p]
         L.fdbm_tfgridnet_forward.restype = c_int
+        L.fdbm_tfgridnet_forward_from.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                                  c_void_p, c_i64, c_void_p, c_void_p]
+        L.fdbm_tfgridnet_forward_from.restype = c_int
         _lib = L
     return _lib
 
@@ -200,6 +205,17 @@ def conv_plan_ex(B, H, W, cout, nk, first_taps):
     v = [c_int() for _ in range(5)]
     lib().fdbm_conv_plan_ex(B, H, W, cout, nk, first_taps, *[ctypes.byref(x) for x in v])
     return dict(zip(("kind", "th", "bm", "bn", "ksplit"), [x.value for x in v]))
+
+
+def log_time(t):
+    """log t of the model time as the float32 the time embedding is fed (GaussianFourierProjection(log t),
+    ncsnpp_v2.py:252-257 / tfgridnet.py:214-216), evaluated on the HOST in float64 and rounded ONCE: the correctly rounded
+    float32 logarithm, whatever the machine.  A float32 `logf` is allowed to be one unit off near a rounding tie, and
+    which neighbour it returns depends on the host's vector ISA: at t = 0.10009 (step 3 of the 30-step fm grid, step 27
+    of the sb grid) the exact logarithm sits 0.4988 ulp from the tie, two hosts disagreed, and that one unit moved
+    sin(2 pi W log t) enough to put the network output 2e-4 from the reference's (tests: test_teacher_forced_all_30_steps)."""
+    t = torch.as_tensor(t).detach().to(device="cpu", dtype=torch.float32)
+    return torch.log(t.to(torch.float64)).to(torch.float32)
 
 
 def _dev_f32(w, device):

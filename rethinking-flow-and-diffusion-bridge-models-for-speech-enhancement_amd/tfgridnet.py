@@ -193,7 +193,7 @@ class HipTFGridNet:
                 raise RuntimeError(self._err())
             self._ws = {key: torch.empty(nb, dtype=torch.uint8, device=self.device)}
         ws = self._ws[key]
-        log_t = torch.log(t.detach().float().cpu()).to(self.device)       # host-evaluated logarithm
+        log_t = hip.log_time(t).to(self.device)       # host-evaluated logarithm
         x, y = x.contiguous(), y.contiguous()
         out = torch.empty_like(x)
         blocks = torch.empty(self.hp["n_layers"], B, T, F, self.hp["emb_dim"], device=self.device) if block_out else None
@@ -203,6 +203,22 @@ class HipTFGridNet:
         if rc:
             raise RuntimeError(self._err())
         return (out, blocks) if block_out else out
+
+    def forward_from(self, block_in, first_block, t):
+        """Teacher-forced entry (fdbm_tfgridnet_forward_from): block_in f32 [B,T,F,C] is the input of block `first_block`
+        (>= 1); -> (final complex spectrogram, every block's output [n_layers,B,T,F,C], rows < first_block unset)."""
+        B, T, F, C = block_in.shape
+        assert block_in.is_cuda and block_in.dtype == torch.float32 and C == self.hp["emb_dim"]
+        nb = int(self.lib.fdbm_tfgridnet_workspace_bytes(ctypes.byref(self.desc), B, F, T))
+        ws = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        log_t = hip.log_time(t).to(self.device)
+        out = torch.empty(B, 1, F, T, dtype=torch.complex64, device=self.device)
+        blocks = torch.full((self.hp["n_layers"], B, T, F, C), float("nan"), device=self.device)
+        rc = self.lib.fdbm_tfgridnet_forward_from(self.ctx, block_in.contiguous().data_ptr(), int(first_block), log_t.data_ptr(),
+                                                  out.data_ptr(), B, F, T, ws.data_ptr(), ws.numel(), blocks.data_ptr(), hip.stream_ptr())
+        if rc:
+            raise RuntimeError(self._err())
+        return out, blocks
 
     def __del__(self):
         try:

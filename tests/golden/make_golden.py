@@ -347,6 +347,68 @@ def gen_teacher(n_steps=30):
     save("teacher_ncsnpp_v2", **out)
 
 
+def teacher_all_state(y, x_end, z, coef):
+    """The regenerable near-trajectory state of a step: (a y + b x_end) + c z in float32, each product and sum rounded
+    on its own (numpy elementwise ops: identical on every machine).  Used by this generator and by the GPU test."""
+    y, x_end, z = (np.asarray(v, dtype=np.complex64) for v in (y, x_end, z))
+    a, b, c = (np.float32(v) for v in coef)
+    return ((a * y + b * x_end) + c * z).astype(np.complex64)
+
+
+def gen_teacher_all(n_steps=30):
+    """ALL N = 30 steps of both bridges, teacher-forced, in a few KB per step.  For step i the state
+    fed to the network is the REGENERABLE projection of the reference's own xt_i onto span{y, x_N, z}: xt_i ~ a_i y +
+    b_i x_N + c_i z (x_N = the reference's final state, kept in full_ncsnpp_v2.npz; z = the prior draw of
+    torch.manual_seed(4321), regenerated by the test with the same host generator; real least-squares coefficients, 3
+    floats per step) - so the test rebuilds the exact input without 31 x 526 KB per bridge.  Stored per step: the
+    coefficients, the reference's s_i = model(state_i, y, t_i) at a seeded 1 % sample of the elements, and its mean / rms
+    over ALL elements (float64) as a checksum-like whole-tensor statistic."""
+    from fdbm.bridge import Bridge
+    import time
+    net = _full_net()
+    y = synth_spec(1, 256, 21)
+    full = dict(np.load(os.path.join(HERE, "full_ncsnpp_v2.npz")))
+    n_el = y.numel()
+    idx = np.sort(np.random.Generator(np.random.Philox(777)).choice(n_el, size=n_el // 100, replace=False)).astype(np.int64)
+    out = dict(sample_idx=idx)
+    for path, sched in (("sb", "bb"), ("fm", "ot")):
+        br = Bridge(path, N=n_steps, noise_schedule=sched, sampler_type="ode_ei")
+        rec = _Recorder(net)
+        torch.manual_seed(4321)
+        z = torch.randn_like(y)                       # what prior_sampling draws first (bridge.py:47)
+        torch.manual_seed(4321)
+        t0 = time.time()
+        with torch.no_grad():
+            final = br.sampler(rec, y)
+        x_end = torch.from_numpy(full[f"{path}_{sched}_ode_ei_N{n_steps}"])
+        print(f" teacher_all {path}: trajectory {time.time() - t0:.1f}s; final vs full_ncsnpp_v2.npz {float((final - x_end).abs().max()):.2e}", flush=True)
+        ts = torch.linspace(br.start_time, br.end_time, n_steps + 1)
+        basis = np.stack([v.numpy().reshape(-1) for v in (y, x_end, z)], 1)                    # [n, 3] complex
+        A = np.concatenate([basis.real, basis.imag], 0).astype(np.float64)
+        coefs, resid, svals, ssamp, smean, srms = [], [], [], [], [], []
+        for i in range(n_steps):
+            xt = rec.xs[i].numpy().reshape(-1)
+            rhs = np.concatenate([xt.real, xt.imag]).astype(np.float64)
+            c, *_ = np.linalg.lstsq(A, rhs, rcond=None)
+            c = c.astype(np.float32)
+            state = teacher_all_state(y.numpy(), x_end.numpy(), z.numpy(), c)
+            resid.append(float(np.abs(state.reshape(-1) - xt).max()))
+            with torch.no_grad():
+                s = net(torch.from_numpy(state), y, ts[i] * torch.ones(1)).numpy().reshape(-1)
+            coefs.append(c)
+            ssamp.append(s[idx])
+            smean.append([float(s.real.astype(np.float64).mean()), float(s.imag.astype(np.float64).mean())])
+            srms.append(float(np.sqrt((np.abs(s).astype(np.float64) ** 2).mean())))
+            print(f"   step {i:2d} t={float(ts[i]):.4f} coef {c} |state - xt_i| {resid[-1]:.2e} rms(s) {srms[-1]:.3f} ({time.time() - t0:.0f}s)", flush=True)
+        out[f"{path}_coef"] = np.stack(coefs)
+        out[f"{path}_state_vs_trajectory"] = np.array(resid)
+        out[f"{path}_s_sample"] = np.stack(ssamp).astype(np.complex64)
+        out[f"{path}_s_mean"] = np.array(smean)
+        out[f"{path}_s_rms"] = np.array(srms)
+        out[f"{path}_t"] = ts[:-1].numpy()
+    save("teacher_all_ncsnpp_v2", **out)
+
+
 def gen_contractive(n_steps=30):
     """Free-running N=30 ode_ei at the BASELINE geometry with the 'contractive' weight profile (output layer x0.01):
     the sampler does not amplify rounding noise, so two fp32 evaluations CAN agree to 1e-4 end to end.  The
@@ -371,6 +433,44 @@ def gen_contractive(n_steps=30):
         out[f"{path}_spread_8v3"] = np.array(float((res[8] - res[3]).abs().max()))
         print(f"   reference spread 8 vs 3 threads: {float((res[8] - res[3]).abs().max()):.3e}", flush=True)
     save("contractive_ncsnpp_v2", **out)
+
+
+def gen_ode_int():
+    """`ode_sampler_int` (bridge.py:115-140: scipy solve_ivp RK45 over the flattened complex state, host round trips) run
+    by the REFERENCE: ncsnpp_v2_5M with the contractive filler, the `samplers` fixture's noisy spectrogram, rtol = atol =
+    1e-3 and 1e-5 (its default), fm/ot and sb/bb at B = 1 (the reference's SB ode() does not broadcast for B > 1).  Stored: the
+    final state and solve_ivp's evaluation count (the reference does not keep it: counted by a wrapper)."""
+    import fdbm.backbones as bb
+    from fdbm.bridge import Bridge
+    import time
+    hp = VARIANTS["ncsnpp_v2_5M"]
+    net = bb.NCSNpp_v2_5M()
+    fill = fill_state_dict(Spec(**hp).param_shapes(), seed=0, profile="contractive")
+    net.load_state_dict({k: torch.from_numpy(v) for k, v in fill.items()})
+    net.eval()
+    y = torch.from_numpy(np.load(os.path.join(HERE, "samplers.npz"))["y"])
+    out = dict(y=y)
+
+    class Counter:
+        def __init__(self):
+            self.n = 0
+
+        def __call__(self, xt, yy, t):
+            self.n += 1
+            return net(xt, yy, t)
+
+    for path, sched in (("fm", "ot"), ("sb", "bb")):
+        for tag, tol in (("", 1e-3), ("_tight", 1e-5)):          # 1e-5 = the reference's default (bridge.py:115)
+            br = Bridge(path, N=5, noise_schedule=sched, sampler_type="ode_int")
+            cnt = Counter()
+            torch.manual_seed(11)
+            t0 = time.time()
+            with torch.no_grad():
+                x = br.sampler(cnt, y, rtol=tol, atol=tol)
+            print(f" ode_int {path} tol {tol:g}: {cnt.n} evaluations, {time.time() - t0:.1f}s, |x| max {float(x.abs().max()):.3f}", flush=True)
+            out[f"{path}_ode_int{tag}"] = x
+            out[f"{path}_nfev{tag}"] = np.array(cnt.n)
+    save("ode_int_5M", **out)
 
 
 # ---- 7. the other registered variants, one forward each from the reference -----------------

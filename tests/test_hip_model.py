@@ -162,7 +162,7 @@ def test_time_embedding_rows_hoisted_out_of_the_step_loop(golden):
     dense_out = prog.dense_out.view(torch.float32)            # (pool buffers are raw bytes)
     rows_fwd = dense_out[: B * R].clone().reshape(B, R)
     ts = torch.cat([t.float() * 0.5, t.float(), t.float() * 0.25]).cpu()      # 3 "steps" of B times, the forward's in the middle
-    tab = prog.dense_table(torch.log(ts).to(DEV).contiguous())       # log t on the host, like HipNCSNpp.forward
+    tab = prog.dense_table(fdbm_amd.hip.log_time(ts).to(DEV).contiguous())       # log t on the host, like HipNCSNpp.forward
     assert tab.shape == (3 * B, R)
     assert torch.equal(tab[B:2 * B], rows_fwd)
     assert not torch.equal(tab[:B], rows_fwd)
@@ -244,6 +244,46 @@ def test_infer_folder_driver(tmp_path):
     # the driver is the documented pipeline and nothing else (and the bf16 path is reproducible)
     enh = infer.Enhancer(str(ckpt), device=DEV, N=3)
     assert np.array_equal(enh(a[None])[0], ea)
+
+
+@pytest.mark.parametrize("mode", ["single", "folder"])
+def test_driver_reproduces_reference_on_bundled_clip(golden, tmp_path, mode):
+    """Driver parity THROUGH the driver (BASELINE configs[0]): the bundled audio_samples/Sample1_Noisy.wav
+    (its PCM is in the fixture) written as a WAV file, a Lightning-format checkpoint of ncsnpp_v2_5M, then
+    `infer.enhance_single` (infer_single.py:53-101: N = 5, sb/bb ode_ei, 0.5 clip rule) - the file it writes must be the
+    reference's x_hat to 2e-4 of full scale.  `folder`: the same file through `infer.enhance_folder` (infer_folder.py:
+    94-121, 0.95 clip rule): identical up to the clip constant (x_hat 0.95 / 0.5 when the rule fired, else equal)."""
+    import argparse
+    from scipy.io import wavfile
+    from fdbm_amd import infer
+    g = golden("config0_sample1")
+    name = "ncsnpp_v2_5M"
+    spec = Spec(**VARIANTS[name])
+    sd = {k: T(v) for k, v in fill_state_dict(spec.param_shapes(), seed=0).items()}
+    ckpt = tmp_path / "model.ckpt"
+    torch.save({"state_dict": {"dnn." + k: v for k, v in sd.items()},
+                "hyper_parameters": dict(backbone=name, bridge="sb", noise_schedule="bb", n_fft=512, hop_length=256,
+                                         window="sqrthann", spec_factor=0.15, spec_abs_exponent=0.5, normalize="noisy")}, ckpt)
+    src = tmp_path / "noisy"
+    src.mkdir()
+    wavfile.write(src / "Sample1_Noisy.wav", 16000, g["pcm"].astype(np.int16))
+    ref = np.asarray(g["x_hat"]).reshape(-1)
+    if mode == "single":
+        out = tmp_path / "out.wav"
+        args = argparse.Namespace(device=["0"], noisy_file=str(src / "Sample1_Noisy.wav"), output_file=str(out), ckpt=str(ckpt),
+                                  sampler_type="ode_ei", sampler_kwargs=None, N=5, fp32=True)
+        assert infer.enhance_single(args) == str(out)
+    else:
+        out = tmp_path / "enhanced" / "Sample1_Noisy.wav"
+        args = argparse.Namespace(device=["0"], test_dir=str(src), enhanced_dir=str(tmp_path / "enhanced"), ckpt=str(ckpt),
+                                  sampler_type="ode_ei", sampler_kwargs=None, N=5, keep_structure=False, fp32=True, batch=1)
+        assert infer.enhance_folder(args) == 1
+        if np.abs(ref).max() == 0.5:                       # the reference's 0.5 rule fired: the folder driver scales to 0.95
+            ref = ref / 0.5 * 0.95
+    sr, x = wavfile.read(out)
+    assert sr == 16000 and x.shape == ref.shape
+    err = float(np.abs(x.astype(np.float64) - ref).max())
+    assert err <= 2e-4, (mode, err, float(np.abs(ref).max()))
 
 
 def test_infer_folder_batched(tmp_path):

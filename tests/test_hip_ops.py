@@ -180,6 +180,45 @@ def test_device_rng_fused_forms_equal_the_materialised_draw():
     assert all(torch.equal(torch.view_as_real(a), torch.view_as_real(b)) for a, b in zip(*outs))
 
 
+def test_rk45_stage_kernels_match_the_torch_expressions():
+    """fdbm_rk45_lincomb / fdbm_rk45_error (the stage arithmetic of ode_sampler_int on the device) against the torch
+    complex128 expressions they replace in fdbm_amd/odeint.py - the same sums in the same order: 1e-15 relative."""
+    import ctypes
+    from fdbm_amd import odeint
+    g = torch.Generator().manual_seed(5)
+    n = (2, 1, 257, 40)
+    y = torch.view_as_complex(torch.randn(*n, 2, generator=g, dtype=torch.float64)).to(DEV)
+    K = [torch.view_as_complex(torch.randn(*n, 2, generator=g, dtype=torch.float64)).to(DEV) for _ in range(7)]
+    h = -0.0371
+    for s_ in range(1, 6):
+        ref = y.clone()
+        dy = K[0] * (odeint._A[s_][0] * h)
+        for j in range(1, s_):
+            dy = dy + K[j] * (odeint._A[s_][j] * h)
+        ref = y + dy
+        out = odeint._lincomb(y, K[:s_], [a * h for a in odeint._A[s_]], 1.0)
+        assert (out - ref).abs().max().item() <= 1e-15 * ref.abs().max().item(), s_
+    acc = K[0] * odeint._B[0]
+    for j in range(1, 6):
+        if odeint._B[j] != 0.0:
+            acc = acc + K[j] * odeint._B[j]
+    y_new = y + h * acc
+    out = odeint._lincomb(y, K[:6], odeint._B, h)
+    assert (out - y_new).abs().max().item() <= 2e-15 * y_new.abs().max().item()
+    scale = 1e-3 + torch.maximum(y.abs(), y_new.abs()) * 1e-3
+    err = K[0] * odeint._E[0]
+    for j in range(1, 7):
+        if odeint._E[j] != 0.0:
+            err = err + K[j] * odeint._E[j]
+    ref_norm = odeint._rms(err * h / scale)
+    got = odeint._error_norm(K, y, y_new, h, 1e-3, 1e-3)
+    assert abs(got - ref_norm) <= 1e-12 * ref_norm
+    with pytest.raises(RuntimeError):
+        ptrs = (ctypes.c_void_p * 8)(*[K[0].data_ptr()] * 8)
+        cs = (ctypes.c_double * 8)(*[1.0] * 8)
+        hip.call("fdbm_rk45_lincomb", y.data_ptr(), y.data_ptr(), ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(cs, ctypes.c_void_p), 8, 1.0, y.numel())
+
+
 def test_pc_moves():
     B = 2
     x, s, y, z = (crnd(B, 1, 257, 16, seed=i) for i in range(4))

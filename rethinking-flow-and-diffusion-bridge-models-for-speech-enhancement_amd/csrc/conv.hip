@@ -494,14 +494,16 @@ extern "C" int fdbm_conv_kc(int dtype) { return dtype != FDBM_F32 ? 64 : 32; }
 // too few tiles to give every CU two workgroups and enough k-steps to share out (opt-in).
 // Kernel-selection policy: bit 0 = halo-patch kernel allowed, bit 1 = wave-per-tap kernel allowed,
 // bit 2 = k-groups in the tap-outer kernel, bit 3 = producer/consumer ring kernel (conv_ring.hip) in place of the
-// halo-patch kernel where it applies.  Default 11, or from the environment (experiments):
-// FDBM_CONV_PATCH=0, FDBM_CONV_TAP=0, FDBM_CONV_RING=0 clear a bit, FDBM_CONV_KG=4 sets bit 2.
+// halo-patch kernel where it applies, bit 4 = 8-row ring tiles wherever they fit (tests), bit 5 = whole-map kernel
+// (conv_small.hip) in place of the wave-per-tap kernel on the smallest maps.  Default 43, or from the environment
+// (experiments): FDBM_CONV_PATCH=0, FDBM_CONV_TAP=0, FDBM_CONV_RING=0, FDBM_CONV_SMALL=0 clear a bit, FDBM_CONV_KG=4 sets bit 2.
 static int g_policy = -1;
 static int g_last_kind = -1;      // kernel family of the most recent fdbm_conv_igemm launch (see fdbm_conv_last_kind)
 static int conv_policy() {
   if (g_policy < 0) {
-    int m = 11;
+    int m = 43;
     const char* e;
+    if ((e = getenv("FDBM_CONV_SMALL")) && e[0] == '0') m &= ~32;
     if ((e = getenv("FDBM_CONV_PATCH")) && e[0] == '0') m &= ~1;
     if ((e = getenv("FDBM_CONV_RING")) && e[0] == '0') m &= ~8;
     if ((e = getenv("FDBM_CONV_TAP")) && e[0] == '0') m &= ~2;
@@ -511,13 +513,14 @@ static int conv_policy() {
   return g_policy;
 }
 // 0 = tap-outer implicit GEMM, 1 = halo-patch, 2 = wave-per-tap, 3 = producer/consumer ring on 16 x 16 pixel tiles,
-// 4 = the same on 8 x 16 pixel tiles, 5 = the 4-channel head kernel; -1 before the first call.
+// 4 = the same on 8 x 16 pixel tiles, 5 = the 4-channel head kernel, 6 = whole-map kernel of the smallest maps; -1 before
+// the first call.
 // For measurement harnesses (bench.py prices each kernel family against its roofline).
 extern "C" int fdbm_conv_last_kind(void) { return g_last_kind; }
 
 extern "C" int fdbm_conv_policy(int mask) {
   const int old = conv_policy();
-  if (mask >= 0) g_policy = mask & 31;
+  if (mask >= 0) g_policy = mask & 63;
   return old;
 }
 
@@ -556,6 +559,8 @@ int fdbm_launch_conv_ring(const ConvParams& p, int dt_in, int dt_out, hipStream_
 bool fdbm_conv_ring_ok(const ConvParams& p, int rows);
 int fdbm_launch_conv_ring8(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                 // conv_ring8.hip
 int fdbm_launch_conv_head(const ConvParams& p, int dt_in, hipStream_t st);                               // conv_head.hip
+int fdbm_launch_conv_small(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                  // conv_small.hip
+bool fdbm_conv_small_ok(const ConvParams& p);
 bool fdbm_conv_head_ok(const ConvParams& p);
 
 // Which kernel runs a conv of this shape: kind 1 = halo-patch 3x3 kernel (conv_patch.hip, tile
@@ -745,6 +750,14 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     static const char* fth = getenv("FDBM_PATCH_TH");          // experiments: "16" keeps the plan's choice
     if (!(fth && fth[0] == '1') && (!a->gn_sums && !gn_units ? true : a->gn_C <= 256)) th = 8;
     return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
+  }
+  if (kind == 2 && (conv_policy() & 32) && a->dt_in != FDBM_F32) {
+    // the smallest maps (4 x 4, 8 x 8 at batch 1): whole map per workgroup, GroupNorm statistics by the consumer (conv_small.hip)
+    ConvParams ps = p;
+    ps.w = a->w_frag;
+    ps.ksplit = 1;
+    ps.partial = reinterpret_cast<float*>(a->acc_ws);          // (diagnostic stamps only)
+    if (fdbm_conv_small_ok(ps)) { g_last_kind = 6; return fdbm_launch_conv_small(ps, a->dt_in, a->dt_out, st); }
   }
   if (kind == 2) {
     p.w = a->w_frag;

@@ -797,17 +797,28 @@ static int launch_ring(const ConvParams& p, hipStream_t st) {
   }
   const int tiles_x = p.W / 16, tiles_y = p.H / R;
   const int tpi = tiles_x * tiles_y, ny = (p.Cout + 127) / 128;
-  // workgroups per image: enough to put one on every CU (256), each then walks tpi / wpi tiles of its image; a layer
-  // of a single channel chunk is not walked (its patch pipeline would reach two tiles ahead)
-  int wpi = (256 + p.B * ny - 1) / (p.B * ny);
+  // workgroups per image: enough to put one on every CU of the device, each then walks tpi / wpi tiles of its image; a
+  // layer of a single channel chunk is not walked (its patch pipeline would reach two tiles ahead)
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n_cu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+               ? prop.multiProcessorCount : 256;
+  }
+  int wpi = (n_cu + p.B * ny - 1) / (p.B * ny);
   if (wpi > tpi) wpi = tpi;
   if (wpi < 1) wpi = 1;
-  if (p.nk <= 9) wpi = tpi;
-  // and so is a layer with 1-tap (shortcut) segments: the weight ring runs on across a tile boundary only when the tile's
-  // k-steps are a multiple of the ring's 3 slots, which 9-tap chunks alone guarantee
-  for (int sg = 0; sg < p.nseg; ++sg)
-    if (p.seg[sg].taps == 1) wpi = tpi;
   { static const char* e = getenv("FDBM_RING_WGS_PER_IMAGE"); if (e && atoi(e) > 0) wpi = atoi(e) < tpi ? atoi(e) : tpi; }   // experiments / tests
+  // The guards come AFTER the override: a workgroup may walk several tiles only where the 3-slot weight ring
+  // stays in phase across a tile boundary - k-steps per tile a multiple of 3, which 9-tap chunks alone guarantee - and
+  // where the patch pipeline's two-chunk look-ahead stays inside the tile (more than one channel chunk)
+  bool one_tap = false;
+  for (int sg = 0; sg < p.nseg; ++sg)
+    if (p.seg[sg].taps == 1) one_tap = true;
+  if (p.nk <= 9 || one_tap) wpi = tpi;
+  FDBM_CHECK(wpi == tpi || (p.nk % 3 == 0 && !one_tap && p.nk > 9),
+             "fdbm_conv_igemm(ring): %d workgroups per image of %d tiles with %d k-steps: the weight ring would lose its phase", wpi, tpi, p.nk);
   dim3 grid((unsigned)(p.B * wpi), (unsigned)ny);
 #ifdef FDBM_STAMPS
   ConvParams pd = p;

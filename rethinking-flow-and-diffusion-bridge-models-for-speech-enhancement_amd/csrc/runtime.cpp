@@ -246,8 +246,10 @@ extern "C" fdbm_ncsnpp_ctx* fdbm_ncsnpp_create_from_program(const void* program,
     if (((uint64_t)v >> 62) != 1) { bad = true; return nullptr; }      // tagged pointers: bit 62 set, bit 63 clear
     const int region = (int)((v >> 60) & 3);
     const int64_t off = v & ((1ll << 60) - 1);
-    if (region == 0 && off <= h->workspace_bytes) return (char*)workspace_dev + off;
-    if (region == 1 && off <= h->weights_bytes) return (char*)weights_dev + off;
+    // (a tagged pointer must START inside its region; the extent of each access is the recorded op's business: program files
+    // are TRUSTED input, produced by fdbm_amd.export from a program that ran - INTEGRATION.md)
+    if (region == 0 && off < h->workspace_bytes) return (char*)workspace_dev + off;
+    if (region == 1 && off < h->weights_bytes) return (char*)weights_dev + off;
     bad = true;
     return nullptr;
   };

@@ -34,6 +34,7 @@ def _weight_tensors(net):
     for v in net.w.values():
         out += [t for t in v.values() if torch.is_tensor(t)]
     out += [t for (_, t) in getattr(net, "_frag", {}).values()]
+    out += [v[1] for v in getattr(net, "_split", {}).values()]            # pre-split weights of the split-precision mode
     out += [net.fourier_w, net.lin1_w, net.lin1_b, net.lin2_w, net.lin2_b, net.dense_w, net.dense_b]
     return out
 
@@ -61,6 +62,11 @@ def export_program(prog):
     w_bytes = lay(w_allocs, 1)
     table.sort()
 
+    def in_table(p):
+        import bisect
+        i = bisect.bisect_right(table, (p, 1 << 62, 9, 0)) - 1
+        return i >= 0 and table[i][0] <= p < table[i][0] + table[i][1] + _ALIGN
+
     def reloc(p):
         if p == 0:
             return 0
@@ -81,8 +87,13 @@ def export_program(prog):
             continue
         for j in range(24):
             v = ops[i].iarg[j]
-            if v >= (1 << 40):                   # device addresses; counts and shapes never get there
+            # A device address is recognised by MEMBERSHIP in one of the program's allocations, not by its magnitude
+            # (ADVICE r2): a value inside an allocation is relocated; counts, shapes and strides (all < 2^32) lie far below
+            # any device mapping; anything else that large is an address this exporter does not know - refuse it.
+            if in_table(v):
                 ops[i].iarg[j] = reloc(v)
+            elif v >= (1 << 32):
+                raise ValueError(f"op {i} (opcode {ops[i].opcode}) argument {j} = {hex(v)} is neither a count nor inside a known allocation")
     convs = (hip.ConvArgs * len(prog.keep_conv))()
     for i, ca in enumerate(prog.keep_conv):
         ctypes.memmove(ctypes.byref(convs[i]), ctypes.byref(ca), ctypes.sizeof(hip.ConvArgs))

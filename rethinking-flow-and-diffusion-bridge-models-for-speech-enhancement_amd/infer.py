@@ -255,10 +255,18 @@ def enhance_files_batched(gpu_id, file_list, args, counter=None):
                 print(f"\nError processing {noisy_file} on GPU {gpu_id}: {e}")
         try:
             outs = enh.enhance_many(waves, batch=args.batch) if waves else []
-        except Exception as e:          # like the reference: report, count, go on (here: the whole window)
-            print(f"\nError processing a window of {len(waves)} files on GPU {gpu_id}: {e}")
-            outs = []
-            names = []
+        except Exception as e:
+            # one bad row (e.g. a clip shorter than n_fft / 2) must not cost its whole window: like the reference and the
+            # one-file-at-a-time path, only the offending file is skipped - the window is redone file by file
+            print(f"\nA window of {len(waves)} files failed on GPU {gpu_id} ({e}); retrying its files one at a time")
+            good_names, outs = [], []
+            for noisy_file, w in zip(names, waves):
+                try:
+                    outs.append(enh(w))
+                    good_names.append(noisy_file)
+                except Exception as e1:
+                    print(f"\nError processing {noisy_file} on GPU {gpu_id}: {e1}")
+            names = good_names
         for noisy_file, x_hat in zip(names, outs):
             out = output_path(noisy_file, args)
             os.makedirs(dirname(out) or ".", exist_ok=True)

@@ -336,6 +336,13 @@ def test_infer_folder_batched(tmp_path):
     for i, n in enumerate(lengths):
         sr, e = wavfile.read(out / f"f{i}.wav")
         assert sr == 16000 and e.shape == (n,) and np.isfinite(e).all()
+    # a file the front-end refuses (shorter than n_fft / 2: reflect padding impossible) costs ITSELF, not its window of
+    # 4 x batch files: the window is redone one file at a time, as the reference's per-file try / except does
+    wavfile.write(src / "zz_too_short.wav", 16000, np.zeros(100, np.float32))
+    out2 = tmp_path / "enhanced2"
+    args.enhanced_dir = str(out2)
+    assert infer.enhance_folder(args) == len(waves)
+    assert not (out2 / "zz_too_short.wav").exists() and all((out2 / f"f{i}.wav").exists() for i in range(len(waves)))
 
 
 def test_infer_driver_with_tfgridnet_checkpoint(tmp_path):

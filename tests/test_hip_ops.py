@@ -518,12 +518,13 @@ CONV_CASES = [
 ]
 
 
-@pytest.fixture(params=[3, 0, 11, 27], ids=["auto", "tapouter", "ring", "ring8"])
+@pytest.fixture(params=[3, 0, 11, 27, 43], ids=["auto", "tapouter", "ring", "ring8", "small"])
 def conv_kernels(request):
     """Every conv case runs under the kernel selection without the ring kernel (halo-patch / wave-per-tap / tap-outer by
-    shape), with the tap-outer implicit GEMM forced, under the default policy (producer / consumer ring kernel where it
-    applies: 16-bit tensors, >= 200 tiles of 16 x 16 pixels, or >= 128 of 8 x 16) and with the ring kernel's 8-row tiles
-    wherever they fit."""
+    shape), with the tap-outer implicit GEMM forced, with the producer / consumer ring kernel where it applies (16-bit
+    tensors, >= 200 tiles of 16 x 16 pixels, or >= 128 of 8 x 16), with the ring kernel's 8-row tiles wherever they fit,
+    and under the DEFAULT policy, which adds the whole-map kernel of the smallest maps (conv_small.hip: 16-bit tensors,
+    the padded map in LDS)."""
     old = hip.conv_policy(request.param)
     yield request.param
     hip.conv_policy(old)
@@ -599,12 +600,13 @@ def test_conv_full_size_linearity(dtype):
         assert (o1[0, :, yy, xx] - ref).abs().max() < tol
 
 
+@pytest.mark.parametrize("policy", [11, 43], ids=["tap", "small"])
 @pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, F32S])
 @pytest.mark.parametrize("HW", [4, 8, 16], ids=["4x4", "8x8", "16x16"])
 @pytest.mark.parametrize("cin,cin1", [(64, 0), (128, 0), (192, 64), (320, 0), (384, 192), (448, 64), (576, 0)],
                          ids=["1", "2", "3+1", "5", "6+3", "7+1", "9"])
-def test_conv_tap_chunk_remainders(cin, cin1, HW, dtype, splitk):
+def test_conv_tap_chunk_remainders(cin, cin1, HW, dtype, splitk, policy):
     """The wave-per-tap kernel keeps 4 register sets of 64-channel chunks in flight on its one-n-tile tiles (groups
     of 4 chunks unrolled, then a 1..3 chunk tail; a load cursor that stops on the workgroup's last chunk): every
     remainder of the chunk count, with and without a 1-tap shortcut segment behind the 9-tap one, with the channel
@@ -623,7 +625,15 @@ def test_conv_tap_chunk_remainders(cin, cin1, HW, dtype, splitk):
         ref = ref + F.conv2d(q(x1), q(w1))
         segs.append((x1, 1)); weights.append(w1)
     assert hip.conv_plan_ex(B, HW, HW, cout, 9 * ((cin + 63) // 64), 9)["kind"] == 2
-    out, _, _ = run_conv(segs, weights, None, run_dtype, splitk=splitk)
+    old = hip.conv_policy(policy)
+    try:
+        out, _, _ = run_conv(segs, weights, None, run_dtype, splitk=splitk)
+        kind = hip.lib().fdbm_conv_last_kind()
+    finally:
+        hip.conv_policy(old)
+    # policy 43 (the default): the whole-map kernel takes the 16-bit cases whose map and channel counts it accepts
+    small_ok = policy == 43 and dtype == torch.bfloat16 and HW <= 8 and cin in (64, 128, 256, 512) and cin1 % 64 == 0
+    assert kind == (6 if small_ok else 2), (kind, small_ok)
     err = (out - ref).abs().max().item()
     assert err < (2e-5 if dtype == torch.float32 else 2e-2), err
 

@@ -8,31 +8,35 @@
 // rows (a dependent global round trip + two barriers + fp64 math), four register sets of look-ahead with their cursor,
 // statistics atomics behind every epilogue.  The maps are tiny, so the lean form is:
 //   workgroup = 8 waves = (16 output channels) x (16 pixels of one image); grid = Cout/16 x H*W/16 x B
-//   * every weight fragment the workgroup will use is requested FIRST (they depend on nothing): wave w owns tap w of the
-//     9-tap segments; tap 8 and the 1-tap (shortcut / NIN) segments are dealt out k-step by k-step over the 8 waves;
-//   * the WHOLE map of the 9-tap sources is staged once (H*W x C items of 16 bytes), its GroupNorm statistics are summed
-//     by the workgroup itself in a fixed order (thread -> LDS partials -> group totals: no statistics buffers read, no
-//     atomics, one barrier), normalised + SiLU'd in registers and written to LDS with a zero border; 1-tap sources: the
-//     workgroup's own 16 pixels, raw;
+//   * EVERY global load of the kernel is requested up front, in straight-line code, from a compact argument block the host
+//     has already reduced to offsets and strides (the first version of this kernel spent 2.4 us of its 7.7 on integer
+//     arithmetic over the general parameter block before its first load: tools/small_timeline.py): the wave's weight
+//     fragments (wave w owns tap w of the 9-tap segments; tap 8 and the 1-tap shortcut / NIN segments are dealt out
+//     k-step by k-step over the 8 waves), the whole map, the GroupNorm parameters of the thread's channels, and the
+//     epilogue's operands (bias, time bias, residual);
+//   * the WHOLE map of the 9-tap sources is staged once (H*W x C items of 16 bytes); its GroupNorm statistics are summed by
+//     the workgroup itself in a fixed order (thread -> LDS partials -> group totals: no statistics buffers read, no
+//     atomics, one barrier); only the rows this workgroup's pixels touch are normalised + SiLU'd (registers) and written
+//     to LDS, inside a zero border; 1-tap sources: the workgroup's own 16 pixels, raw - or, when they carry the
+//     GroupNorm (the attention block's NIN), staged like a 9-tap source and multiplied at the centre tap only;
 //   * one pass of MFMAs per wave straight from LDS (row stride C + 8 elements: conflict-free b128), partial accumulators
-//     summed through LDS, shared epilogue (conv_epilogue4: bias, time bias, residual, scale, Combine, upsampled residual)
-//     and the output's unit statistics for consumers that still read them (resampling, larger maps).
+//     summed through LDS, epilogue by wave 0 (the arithmetic of conv_epilogue4 on the prefetched operands) and the
+//     output's unit statistics for the consumers that still read them (resampling, larger maps).
 // Results: the same convolution as every other kernel of fdbm_conv_igemm; GroupNorm mean / variance from fp32 sums over
-// H*W*cpg <= 1 024 values in a fixed order (the producers' fp64 unit sums are not read).
+// H*W*cpg <= 2 048 values in a fixed order (the producers' fp64 unit sums are not read).
 // Roofline: latency (these launches hold < 0.1 us of MFMA work per CU); selected by fdbm_conv_igemm for 16-bit tensors when
 // the padded map fits the LDS (fdbm_conv_small_ok).
 #include "conv_common.h"
 
 #define SM_NTHR 512
-#define SM_MAXW 24            // weight fragments (uint4) a wave may hold: 16 own-tap k-steps... see small_plan
 
 // Diagnostic build only (-DFDBM_STAMPS, tools/small_timeline.py): workgroup (0, 0, 0) writes realtime-clock stamps (100 MHz)
 // of its phases into the scratch the caller passed as acc_ws.  The product library has none of it.
 #ifdef FDBM_STAMPS
 #define SSTAMP(i)                                                                                         \
   do {                                                                                                    \
-    if (p.partial && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)            \
-      reinterpret_cast<unsigned long long*>(p.partial)[i] = __builtin_amdgcn_s_memrealtime();             \
+    if (a.stamps && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)             \
+      a.stamps[i] = __builtin_amdgcn_s_memrealtime();                                                     \
   } while (0)
 #else
 #define SSTAMP(i)
@@ -40,249 +44,327 @@
 
 namespace {
 
-struct SmallPlan {
-  int c9, c1;                 // channels of the 9-tap / 1-tap segments (sums)
-  int n9, n1;                 // number of 9-tap / 1-tap segments
-  int ks9, ks1;               // 32-channel k-steps of one tap of the 9-tap segments / of the 1-tap segments
-  int pooled;                 // k-steps dealt out over the waves: tap 8's + the 1-tap segments'
-  int lds_bytes;
+// everything the kernel needs, already reduced by the host (element counts are in elements of T)
+struct SmallArgs {
+  // weights (fragment-major: a (k-step of 64 channels, 16-channel n-tile) block is 1 024 elements)
+  const void* w;
+  int64_t wb9[2], wtap9[2];           // staged segment s: offset of its tap 0 / chunk 0 / n-tile 0 block; stride between taps
+  int64_t wb1[2];                     // raw 1-tap segment s: offset of its chunk 0 / n-tile 0 block
+  int64_t wchunk;                     // stride between consecutive 64-channel chunks (= CoutPad / 16 blocks)
+  // sources
+  const void* src9[2];                // whole-map ("staged") segments, + coff
+  const void* src1[2];                // raw 1-tap segments, + coff
+  int sC9[2], sC1[2];                 // their pixel strides
+  int c9_0, c1_0;                     // channels of the first staged / first raw segment (the second starts there)
+  int c9, c1;                         // staged / raw channels in all
+  int taps9;                          // 9: the staged segments are 3x3 taps; 1: 1-tap segments that carry the GroupNorm (centre tap only)
+  int ks1;                            // 32-channel k-steps of the raw 1-tap segments
+  int pooled;                         // k-steps dealt out over the waves
+  int H, W, HW;
+  int a9_bytes, a1_bytes;
+  // GroupNorm over the staged channels
+  const float* gamma;
+  const float* beta;
+  int cpg, silu;
+  float eps, inv_count;
+  // epilogue
+  const float* bias;
+  const float* tbias;
+  int tb_stride;
+  const void* res;
+  float scale;
+  int Cout;
+  unsigned long long* stamps;
 };
 
-static bool small_plan(const ConvParams& p, SmallPlan* sp) {
-  SmallPlan s;
-  memset(&s, 0, sizeof(s));
+static bool small_plan(const ConvParams& p, SmallArgs* out, int* lds_bytes) {
+  SmallArgs a;
+  memset(&a, 0, sizeof(a));
+  const bool gn = p.gn_sums != nullptr;
+  // segment classes: "staged" = whole map in LDS (the 9-tap segments; or, when a GroupNorm covers them, the 1-tap ones),
+  // "raw" = 1-tap segments without GroupNorm (this workgroup's 16 pixels)
+  int n9 = 0, nstaged = 0;
   bool seen1 = false;
   for (int i = 0; i < p.nseg; ++i) {
     if (p.seg[i].cin % 64 != 0 || p.seg[i].coff % 8 != 0 || p.seg[i].C % 8 != 0) return false;
-    if (p.seg[i].taps == 9) { if (seen1) return false; s.c9 += p.seg[i].cin; ++s.n9; }
-    else { seen1 = true; s.c1 += p.seg[i].cin; ++s.n1; }
+    if (p.seg[i].taps == 9) { if (seen1) return false; ++n9; } else { seen1 = true; }
   }
-  if (s.c9 > 512 || s.c1 > 512 || s.n9 > 2 || s.n1 > 2) return false;
-  const int HW = p.H * p.W;
-  if (HW % 16 != 0 || HW > 128 || p.W < 2) return false;
-  if (HW * (s.c9 / 8) > 8 * SM_NTHR) return false;                 // at most 8 staged items per thread (registers)
-  if (s.c9 && (SM_NTHR % (s.c9 / 8)) != 0) return false;           // a thread keeps ONE item column: c9 = 64 | 128 | 256 | 512
-  s.ks9 = s.c9 / 32;
-  s.ks1 = s.c1 / 32;
-  s.pooled = (s.c9 ? s.ks9 : 0) + s.ks1;
-  // per wave: its own tap's k-steps + its share of the pooled ones
-  if (s.ks9 + (s.pooled + 7) / 8 > SM_MAXW) return false;
-  // GroupNorm prologue: groups made of whole 16-byte items, all flagged segments are 9-tap ones covering c9
-  if (p.gn_sums) {
-    if (p.gn_C != s.c9 || s.c9 == 0) return false;
-    const int cpg = p.gn_C / p.gn_G;
-    if ((cpg % 8 != 0 && cpg != 4) || p.gn_G > 128) return false;   // groups of whole 16-byte items, or of half an item
-    for (int i = 0; i < p.nseg; ++i)
-      if ((p.seg_gn[i] >= 0) != (p.seg[i].taps == 9)) return false;
+  const bool gn1 = gn && n9 == 0;                                   // the GroupNorm sits on 1-tap segments (NIN)
+  a.taps9 = gn1 ? 1 : 9;
+  int kb = 0;
+  const int64_t blk = 1024, ntq = p.CoutPad / 16;
+  for (int i = 0; i < p.nseg; ++i) {
+    const fdbm_conv_seg& sg = p.seg[i];
+    const int nch = sg.cin / 64;
+    const bool flagged = p.seg_gn[i] >= 0;
+    const bool staged = sg.taps == 9 || (gn1 && flagged);
+    if (gn && sg.taps == 9 && !flagged) return false;               // (a 9-tap segment outside the GroupNorm: not in this network)
+    if (gn && !gn1 && sg.taps == 1 && flagged) return false;
+    if (staged) {
+      if (nstaged >= 2) return false;
+      a.src9[nstaged] = reinterpret_cast<const unsigned char*>(sg.src) + (int64_t)sg.coff * 2;
+      a.sC9[nstaged] = sg.C;
+      a.wb9[nstaged] = (int64_t)kb * ntq * blk;
+      a.wtap9[nstaged] = (int64_t)nch * ntq * blk;
+      if (nstaged == 0) a.c9_0 = sg.cin;
+      a.c9 += sg.cin;
+      ++nstaged;
+    } else {
+      const int r = (a.c1 == 0) ? 0 : 1;
+      if (r == 1 && a.src1[1]) return false;
+      a.src1[r] = reinterpret_cast<const unsigned char*>(sg.src) + (int64_t)sg.coff * 2;
+      a.sC1[r] = sg.C;
+      a.wb1[r] = (int64_t)kb * ntq * blk;
+      if (r == 0) a.c1_0 = sg.cin;
+      a.c1 += sg.cin;
+    }
+    kb += sg.taps * nch;
   }
-  const int act9 = s.c9 ? (p.H + 2) * (p.W + 2) * (s.c9 + 8) * 2 : 0;
-  const int act1 = s.c1 ? 16 * (s.c1 + 8) * 2 : 0;
-  s.lds_bytes = act9 + act1 + 8 * 64 * 16 /*partials*/ + SM_NTHR * 16 /*stat partials*/ + 64 * 8 * 2 /*out stats*/ + 64;
-  if (s.lds_bytes > 150 * 1024) return false;
-  *sp = s;
+  if (a.c1 > 512) return false;
+  if (a.c9 != 0 && a.c9 != 256 && a.c9 != 512) return false;      // (the kernel is instantiated for 8 | 16 staged k-steps)
+  if (a.c9 == 0 && a.c1 == 0) return false;
+  a.wchunk = ntq * blk;
+  a.H = p.H; a.W = p.W; a.HW = p.H * p.W;
+  if (a.HW % 16 != 0 || a.HW > 128 || p.W < 2) return false;
+  if (a.c9 && a.HW * (a.c9 / 8) > 8 * SM_NTHR) return false;       // at most 8 staged items per thread (registers)
+  a.ks1 = a.c1 / 32;
+  a.pooled = (a.c9 ? a.c9 / 32 : 0) + a.ks1;                       // tap 8 (or the centre tap) of the staged channels + the raw ones
+  if (a.pooled > 32) return false;
+  if (gn) {
+    if (p.gn_C != a.c9 || a.c9 == 0) return false;
+    a.cpg = p.gn_C / p.gn_G;
+    if ((a.cpg % 8 != 0 && a.cpg != 4) || p.gn_G > 128) return false;   // groups of whole 16-byte items, or of half an item
+    a.gamma = p.gn_gamma; a.beta = p.gn_beta; a.silu = p.gn_silu; a.eps = p.gn_eps;
+    a.inv_count = 1.0f / (float)(a.HW * a.cpg);
+  }
+  if (p.res_lo || p.comb_pyr) return false;                        // (upsampled residual / Combine epilogues stay on the general kernels)
+  a.a9_bytes = a.c9 ? (p.H + 2) * (p.W + 2) * (a.c9 + 8) * 2 : 0;
+  a.a1_bytes = a.c1 ? 16 * (a.c1 + 8) * 2 : 0;
+  *lds_bytes = a.a9_bytes + a.a1_bytes + 8 * 64 * 16 /*partials*/ + SM_NTHR * 16 /*stat partials*/ + 64 * 8 * 2 /*out stats*/ + 64;
+  if (*lds_bytes > 150 * 1024) return false;
+  a.w = p.w;
+  a.bias = p.bias; a.tbias = p.tbias; a.tb_stride = p.tbias_stride; a.res = p.res; a.scale = p.scale; a.Cout = p.Cout;
+  a.stamps = reinterpret_cast<unsigned long long*>(p.partial);
+  *out = a;
   return true;
 }
 
-// one 16-byte load of activations
 template <typename T>
 __device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <typename T, typename TO, bool GNP>
-__global__ void __launch_bounds__(SM_NTHR) conv_small_kernel(const ConvParams p, const SmallPlan sp) {
+// KS9: staged channels / 32 (8 | 16; 0: no staged segment).  NRAW: staged 16-byte items per thread (1 | 2 | 4 | 8).
+template <typename T, typename TO, bool GNP, int KS9, int NRAW>
+__global__ void __launch_bounds__(SM_NTHR) conv_small_kernel(const SmallArgs a, TO* __restrict__ out, double* __restrict__ stat_out,
+                                                             int stat_G, int stat_nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int H = p.H, W = p.W, HW = H * W, PW = W + 2;
-  const int RS9 = sp.c9 + 8, RS1 = sp.c1 + 8;                      // LDS row strides (elements)
+  constexpr int C9 = KS9 * 32;
+  constexpr int RS9 = C9 + 8;                                      // LDS row stride of the staged map (elements)
+  constexpr int IPP = C9 ? C9 / 8 : 64;                            // staged items per pixel
+  constexpr int PPASS = SM_NTHR / IPP;                             // pixels per pass
+  const int W = a.W, HW = a.HW, PW = W + 2;
+  const int RS1 = a.c1 + 8;
   T* s_a9 = reinterpret_cast<T*>(smem);                            // [(H+2)(W+2)][RS9] activated, zero border
-  const int a9_bytes = sp.c9 ? (H + 2) * PW * RS9 * 2 : 0;
-  T* s_a1 = reinterpret_cast<T*>(smem + a9_bytes);                 // [16][RS1] raw
-  const int a1_bytes = sp.c1 ? 16 * RS1 * 2 : 0;
-  f32x4* s_red = reinterpret_cast<f32x4*>(smem + a9_bytes + a1_bytes);          // [8 waves][64 lanes]
-  f32x4* s_part = s_red + 8 * 64;                                                // [parts][item columns] = one per thread: (sum, sumsq) of channels 0-3 | 4-7
-  double* s_ostat = reinterpret_cast<double*>(s_part + SM_NTHR);                 // [64][2] output unit statistics
+  T* s_a1 = reinterpret_cast<T*>(smem + a.a9_bytes);               // [16][RS1] raw
+  f32x4* s_red = reinterpret_cast<f32x4*>(smem + a.a9_bytes + a.a1_bytes);       // [8 waves][64 lanes]
+  f32x4* s_part = s_red + 8 * 64;                                  // one per thread: (sum, sumsq) of channels 0-3 | 4-7 of its items
+  double* s_ostat = reinterpret_cast<double*>(s_part + SM_NTHR);   // [64][2] output unit statistics
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frow = lane & 15, fk = lane >> 4;
   const int ntile = blockIdx.x, pgroup = blockIdx.y, b = blockIdx.z;
   const int64_t img = (int64_t)b * HW;
-  const T* wbase = reinterpret_cast<const T*>(p.w);                // fragment-major [kidx][CoutPad/16][8 chunks][16 rows][8]
-
   SSTAMP(0);
-  // ---- 1. every weight fragment of this wave, requested before anything else --------------------------------------------
-  // k-step numbering: one tap of the 9-tap segments = ks9 steps of 32 channels (segment after segment); the 1-tap segments
-  // ks1 steps.  Packed weights: kidx = kbase_seg + tap * nch_seg + chunk (64-channel chunks), a 32-channel step is k-half
-  // (step & 1) of chunk (step >> 1): lane (frow, fk) reads 16-byte chunk 4 * khalf + fk of row frow.
-  auto wfrag_ptr = [&](int seg, int tap, int step_in_seg) __attribute__((always_inline)) {
-    int kb = 0;
-    for (int i = 0; i < seg; ++i) kb += SEG_FIELD(p, i, taps) * (SEG_FIELD(p, i, cin) / 64);
-    const int nch = SEG_FIELD(p, seg, cin) / 64;
-    const int kidx = kb + tap * nch + (step_in_seg >> 1);
-    return wbase + (((int64_t)kidx * (p.CoutPad / 16) + ntile) * 8 + (step_in_seg & 1) * 4 + fk) * 128 + frow * 8;
-  };
-  // segment of a k-step index within the 9-tap (or 1-tap) channel axis
-  const int c9_0 = sp.n9 >= 1 ? p.seg[0].cin : 0;                  // channels of the first 9-tap segment
-  const int c1_0 = sp.n1 >= 1 ? SEG_FIELD(p, sp.n9, cin) : 0;      // ... of the first 1-tap segment
-  uint4 wown[16];                                                  // this wave's tap (taps 0..7), k-steps 0 .. ks9-1
-  uint4 wpool[4];                                                  // pooled k-steps j = wave, wave + 8, ... (<= 32 of them)
+
+  // ---- 1. every global load of the kernel, straight-line -----------------------------------------------------------------------
+  // weights: lane (frow, fk) reads 16-byte chunk 4 * khalf + fk of row frow of a (chunk, n-tile) block
+  const T* wl = reinterpret_cast<const T*>(a.w) + (int64_t)ntile * 1024 + fk * 128 + frow * 8;
+  [[maybe_unused]] uint4 wown[KS9 ? KS9 : 1];                      // this wave's tap (9-tap staged segments), k-steps 0 .. KS9-1
+  if constexpr (KS9 > 0) {
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    wown[k] = uint4{0u, 0u, 0u, 0u};
-    if (k < sp.ks9) {
+    for (int k = 0; k < KS9; ++k) {
       const int ch = k * 32;
-      const int seg = ch < c9_0 ? 0 : 1;
-      wown[k] = ld16(wfrag_ptr(seg, wave, (ch - (seg ? c9_0 : 0)) / 32));
+      const bool s1 = ch >= a.c9_0;                                 // (scalar: which staged segment)
+      // (centre-tap form: the staged segments have ONE tap and these fragments go unused - read tap 0, stay inside the buffer)
+      const int64_t base = (s1 ? a.wb9[1] : a.wb9[0]) + (int64_t)(a.taps9 == 9 ? wave : 0) * (s1 ? a.wtap9[1] : a.wtap9[0]);
+      const int rel = ch - (s1 ? a.c9_0 : 0);
+      wown[k] = ld16(wl + base + (int64_t)(rel >> 6) * a.wchunk + ((rel >> 5) & 1) * 512);
     }
   }
+  uint4 wpool[4];                                                   // pooled k-steps j = wave, wave + 8, ... (clamped: every load is issued)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    wpool[k] = uint4{0u, 0u, 0u, 0u};
-    const int j = wave + 8 * k;
-    if (j < sp.pooled) {
-      if (sp.c9 && j < sp.ks9) {                                   // tap 8 of the 9-tap segments
-        const int ch = j * 32;
-        const int seg = ch < c9_0 ? 0 : 1;
-        wpool[k] = ld16(wfrag_ptr(seg, 8, (ch - (seg ? c9_0 : 0)) / 32));
-      } else {                                                     // a 1-tap segment's k-step
-        const int ch = (j - (sp.c9 ? sp.ks9 : 0)) * 32;
-        const int s1 = ch < c1_0 ? 0 : 1;
-        wpool[k] = ld16(wfrag_ptr(sp.n9 + s1, 0, (ch - (s1 ? c1_0 : 0)) / 32));
-      }
+    const int j = min(wave + 8 * k, a.pooled - 1);
+    int64_t off;
+    if (KS9 > 0 && j < KS9) {                                      // tap 8 of a 9-tap segment / the only tap of a GroupNorm'd 1-tap one
+      const int ch = j * 32;
+      const bool s1 = ch >= a.c9_0;
+      const int rel = ch - (s1 ? a.c9_0 : 0);
+      off = (s1 ? a.wb9[1] : a.wb9[0]) + (a.taps9 == 9 ? 8 : 0) * (s1 ? a.wtap9[1] : a.wtap9[0]) + (int64_t)(rel >> 6) * a.wchunk + ((rel >> 5) & 1) * 512;
+    } else {                                                       // a raw 1-tap segment's k-step
+      const int ch = (j - KS9) * 32;
+      const bool s1 = ch >= a.c1_0;
+      const int rel = ch - (s1 ? a.c1_0 : 0);
+      off = (s1 ? a.wb1[1] : a.wb1[0]) + (int64_t)(rel >> 6) * a.wchunk + ((rel >> 5) & 1) * 512;
     }
+    wpool[k] = ld16(wl + off);
   }
-
-  SSTAMP(1);
-  // ---- 2. stage the map ----------------------------------------------------------------------------------------------------
-  // items of 16 bytes: (pixel, 8 channels of the concatenated 9-tap channel axis); thread tid keeps item column tid % ipp
-  const int ipp = sp.c9 ? sp.c9 / 8 : 64;                          // items per pixel (32 | 64; no 9-tap segment: unused)
-  const int icol = tid % ipp, ppass = SM_NTHR / ipp;               // pixels per pass (16 | 8)
-  uint4 raw[8];
-  {
+  // the staged map: thread tid keeps item column tid % IPP (8 channels) of pixels tid / IPP + PPASS j
+  const int icol = tid % IPP;
+  [[maybe_unused]] uint4 raw[NRAW];
+  if constexpr (KS9 > 0) {
     const int ch = icol * 8;
-    const int seg = ch < c9_0 ? 0 : 1;
-    const T* src = reinterpret_cast<const T*>(SEG_FIELD(p, seg, src)) + img * SEG_FIELD(p, seg, C) + SEG_FIELD(p, seg, coff) + (ch - (seg ? c9_0 : 0));
-    const int sC = SEG_FIELD(p, seg, C);
+    const bool s1 = ch >= a.c9_0;
+    const T* src = reinterpret_cast<const T*>(s1 ? a.src9[1] : a.src9[0]) + img * (s1 ? a.sC9[1] : a.sC9[0]) + (ch - (s1 ? a.c9_0 : 0));
+    const int sC = s1 ? a.sC9[1] : a.sC9[0];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      raw[j] = uint4{0u, 0u, 0u, 0u};
-      const int px = tid / ipp + ppass * j;
-      if (sp.c9 && px < HW) raw[j] = ld16(src + (int64_t)px * sC);
+    for (int j = 0; j < NRAW; ++j) {
+      const int px = min(tid / IPP + PPASS * j, HW - 1);            // (clamped: absent items reload the last pixel and are masked below)
+      raw[j] = ld16(src + (int64_t)px * sC);
     }
   }
-  // 1-tap sources: this workgroup's 16 pixels, raw
+  // raw 1-tap sources: this workgroup's 16 pixels (<= 1 024 items, 2 per thread; clamped)
   uint4 raw1[2];
   {
-    const int ipp1 = sp.c1 / 8;                                    // <= 64 items per pixel: 16 x 64 = 1 024 items, 2 per thread
+    const int ipp1 = max(a.c1 / 8, 1);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      raw1[j] = uint4{0u, 0u, 0u, 0u};
-      const int q = tid + SM_NTHR * j;
-      if (sp.c1 && q < 16 * ipp1) {
-        const int px = pgroup * 16 + q / ipp1, ch = (q % ipp1) * 8;
-        const int s1 = ch < c1_0 ? 0 : 1;
-        const int seg = sp.n9 + s1;
-        raw1[j] = ld16(reinterpret_cast<const T*>(SEG_FIELD(p, seg, src)) + (img + px) * SEG_FIELD(p, seg, C) + SEG_FIELD(p, seg, coff) + (ch - (s1 ? c1_0 : 0)));
-      }
+      const int q = min(tid + SM_NTHR * j, 16 * ipp1 - 1);
+      const int px = pgroup * 16 + q / ipp1, ch = (q % ipp1) * 8;
+      const bool s1 = ch >= a.c1_0;
+      const T* base1 = reinterpret_cast<const T*>(a.c1 ? (s1 ? a.src1[1] : a.src1[0]) : a.w);   // (no raw segment: a harmless address)
+      raw1[j] = ld16(base1 + (a.c1 ? (img + px) * (s1 ? a.sC1[1] : a.sC1[0]) + (ch - (s1 ? a.c1_0 : 0)) : 0));
     }
   }
-  // GroupNorm parameters of this thread's 8 channels (its items all sit in item column icol)
-  float gam[8], bet[8];
+  // GroupNorm parameters of this thread's 8 channels
+  [[maybe_unused]] f32x4 g0, g1, b0, b1;
   if constexpr (GNP) {
-    const f32x4 g0 = *reinterpret_cast<const f32x4*>(p.gn_gamma + icol * 8), g1 = *reinterpret_cast<const f32x4*>(p.gn_gamma + icol * 8 + 4);
-    const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.gn_beta + icol * 8), b1 = *reinterpret_cast<const f32x4*>(p.gn_beta + icol * 8 + 4);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { gam[k] = g0[k]; gam[4 + k] = g1[k]; bet[k] = b0[k]; bet[4 + k] = b1[k]; }
+    g0 = *reinterpret_cast<const f32x4*>(a.gamma + icol * 8); g1 = *reinterpret_cast<const f32x4*>(a.gamma + icol * 8 + 4);
+    b0 = *reinterpret_cast<const f32x4*>(a.beta + icol * 8); b1 = *reinterpret_cast<const f32x4*>(a.beta + icol * 8 + 4);
   }
-  // zero the padded map (the border stays zero: padding AFTER the activation) and the output statistics
-  for (int i = tid; i < a9_bytes / 16; i += SM_NTHR) reinterpret_cast<uint4*>(s_a9)[i] = uint4{0u, 0u, 0u, 0u};
-  if (p.stat_out)
-    for (int i = tid; i < 128; i += SM_NTHR) s_ostat[i] = 0.0;
+  // the epilogue's operands (used by wave 0 only; absent ones read a zero vector: no load behind a branch)
+  const int pme = pgroup * 16 + frow;
+  const int n_out = ntile * 16 + fk * 4;
+  const bool live = n_out < a.Cout;
+  const int n_ld = live ? n_out : 0;
+  const f32x4 e_bias = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + n_ld : g_conv_zero);
+  const f32x4 e_tb = *reinterpret_cast<const f32x4*>(a.tbias ? a.tbias + (int64_t)b * a.tb_stride + n_ld : g_conv_zero);
+  float e_res[4];
+  OutVec<TO>::load(a.res ? reinterpret_cast<const TO*>(a.res) + (img + pme) * a.Cout + n_ld : reinterpret_cast<const TO*>(g_conv_zero), e_res);
+  SSTAMP(1);
 
+  // ---- 2. zero the padded map and the output statistics (LDS only) ---------------------------------------------------------------
+  for (int i = tid; i < a.a9_bytes / 16; i += SM_NTHR) reinterpret_cast<uint4*>(s_a9)[i] = uint4{0u, 0u, 0u, 0u};
+  if (stat_out)
+    for (int i = tid; i < 128; i += SM_NTHR) s_ostat[i] = 0.0;
   SSTAMP(2);
-  // ---- 3. GroupNorm statistics by the workgroup itself, fixed order --------------------------------------------------------
-  float mean_lo = 0.f, rstd_lo = 1.f, mean_hi = 0.f, rstd_hi = 1.f;        // of the item's channels 0-3 / 4-7
-  if constexpr (GNP) {
+
+  // ---- 3. GroupNorm statistics by the workgroup itself, fixed order ------------------------------------------------------------------
+  [[maybe_unused]] float mean_lo = 0.f, rstd_lo = 1.f, mean_hi = 0.f, rstd_hi = 1.f;      // of the item's channels 0-3 / 4-7
+  if constexpr (GNP && KS9 > 0) {
     f32x4 ps = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const typename V16<T>::x8 e = *reinterpret_cast<const typename V16<T>::x8*>(&raw[j]);
+    for (int j = 0; j < NRAW; ++j) {
+      if (tid / IPP + PPASS * j < HW) {
+        const typename V16<T>::x8 e = *reinterpret_cast<const typename V16<T>::x8*>(&raw[j]);
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {                                // (absent items are zero)
-        const float a = (float)e[k], c = (float)e[4 + k];
-        ps[0] += a; ps[1] += a * a; ps[2] += c; ps[3] += c * c;
+        for (int k = 0; k < 4; ++k) {
+          const float x = (float)e[k], y = (float)e[4 + k];
+          ps[0] += x; ps[1] += x * x; ps[2] += y; ps[3] += y * y;
+        }
       }
     }
-    s_part[tid] = ps;                                              // (= [tid / ipp][icol])
+    s_part[tid] = ps;                                              // = [tid / IPP][icol]
     __syncthreads();
-    const int cpg = p.gn_C / p.gn_G;
-    if (cpg == 4) {                                                // a group = half an item
-      f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < ppass; ++q) t += s_part[q * ipp + icol];
-      const float inv = 1.0f / (float)(HW * 4);
-      mean_lo = t[0] * inv; mean_hi = t[2] * inv;
-      rstd_lo = __builtin_amdgcn_rsqf(fmaxf(t[1] * inv - mean_lo * mean_lo, 0.f) + p.gn_eps);
-      rstd_hi = __builtin_amdgcn_rsqf(fmaxf(t[3] * inv - mean_hi * mean_hi, 0.f) + p.gn_eps);
-    } else {                                                       // a group = ipg whole items
-      const int ipg = cpg / 8;
-      const int i0 = (icol / ipg) * ipg;
-      float t1 = 0.f, t2 = 0.f;
-      for (int q = 0; q < ppass; ++q)
-        for (int i = 0; i < ipg; ++i) { const f32x4 v = s_part[q * ipp + i0 + i]; t1 += v[0] + v[2]; t2 += v[1] + v[3]; }
-      const float inv = 1.0f / (float)(HW * cpg);
-      mean_lo = mean_hi = t1 * inv;
-      rstd_lo = rstd_hi = __builtin_amdgcn_rsqf(fmaxf(t2 * inv - mean_lo * mean_lo, 0.f) + p.gn_eps);
+    // the PPASS partial sums of the thread's group, all reads in flight at once
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (a.cpg <= 8) {                                              // a group = one item (8 channels) or half an item (4)
+      f32x4 v[PPASS];
+#pragma unroll
+      for (int q = 0; q < PPASS; ++q) v[q] = s_part[q * IPP + icol];
+#pragma unroll
+      for (int q = 0; q < PPASS; ++q) t += v[q];
+      if (a.cpg == 8) { t[0] += t[2]; t[1] += t[3]; t[2] = t[0]; t[3] = t[1]; }
+    } else {                                                       // a group = ipg whole items (16 channels: 2)
+      const int ipg = a.cpg >> 3, i0 = (icol / ipg) * ipg;
+      for (int i = 0; i < ipg; ++i) {
+        f32x4 v[PPASS];
+#pragma unroll
+        for (int q = 0; q < PPASS; ++q) v[q] = s_part[q * IPP + i0 + i];
+#pragma unroll
+        for (int q = 0; q < PPASS; ++q) t += v[q];
+      }
+      t[0] += t[2]; t[1] += t[3]; t[2] = t[0]; t[3] = t[1];
     }
+    mean_lo = t[0] * a.inv_count; mean_hi = t[2] * a.inv_count;
+    rstd_lo = __builtin_amdgcn_rsqf(fmaxf(t[1] * a.inv_count - mean_lo * mean_lo, 0.f) + a.eps);
+    rstd_hi = __builtin_amdgcn_rsqf(fmaxf(t[3] * a.inv_count - mean_hi * mean_hi, 0.f) + a.eps);
   } else {
     __syncthreads();                                               // (the zeroing above precedes the interior writes)
   }
   SSTAMP(3);
-  // ---- 4. normalise + SiLU in registers, write the interior ----------------------------------------------------------------
+
+  // ---- 4. normalise + SiLU in registers; only the rows this workgroup's pixels touch go to LDS ----------------------------------------
+  if constexpr (KS9 > 0) {
+    const int r_lo = (pgroup * 16) / W - 1, r_hi = (pgroup * 16 + 15) / W + 1;      // (for the centre-tap form one row less would do)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const int px = tid / ipp + ppass * j;
-    if (sp.c9 && px < HW) {
-      uint4 v = raw[j];
-      if constexpr (GNP) {
-        typename V16<T>::x8 e = *reinterpret_cast<typename V16<T>::x8*>(&v);
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          float y = ((float)e[k] - (k < 4 ? mean_lo : mean_hi)) * (k < 4 ? rstd_lo : rstd_hi) * gam[k] + bet[k];
-          if (p.gn_silu) y = silu_f(y);
-          e[k] = (T)y;
-        }
-        v = *reinterpret_cast<uint4*>(&e);
-      }
+    for (int j = 0; j < NRAW; ++j) {
+      const int px = tid / IPP + PPASS * j;
       const int py = px / W, pxx = px - py * W;
-      *reinterpret_cast<uint4*>(s_a9 + ((py + 1) * PW + pxx + 1) * RS9 + icol * 8) = v;
+      if (px < HW && py >= r_lo && py <= r_hi) {
+        uint4 v = raw[j];
+        if constexpr (GNP) {
+          typename V16<T>::x8 e = *reinterpret_cast<typename V16<T>::x8*>(&v);
+          float y[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            y[k] = ((float)e[k] - mean_lo) * rstd_lo * g0[k] + b0[k];
+            y[4 + k] = ((float)e[4 + k] - mean_hi) * rstd_hi * g1[k] + b1[k];
+          }
+          if (a.silu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) y[k] = silu_f(y[k]);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) e[k] = (T)y[k];
+          v = *reinterpret_cast<uint4*>(&e);
+        }
+        *reinterpret_cast<uint4*>(s_a9 + ((py + 1) * PW + pxx + 1) * RS9 + icol * 8) = v;
+      }
     }
   }
+  if (a.c1) {
+    const int ipp1 = a.c1 / 8;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int q = tid + SM_NTHR * j;
-    const int ipp1 = sp.c1 / 8;
-    if (sp.c1 && q < 16 * ipp1) *reinterpret_cast<uint4*>(s_a1 + (q / ipp1) * RS1 + (q % ipp1) * 8) = raw1[j];
+    for (int j = 0; j < 2; ++j) {
+      const int q = tid + SM_NTHR * j;
+      if (q < 16 * ipp1) *reinterpret_cast<uint4*>(s_a1 + (q / ipp1) * RS1 + (q % ipp1) * 8) = raw1[j];
+    }
   }
   __syncthreads();
-
   SSTAMP(4);
-  // ---- 5. MFMAs: 16 output channels (rows of the weight fragments) x this workgroup's 16 pixels (columns) -------------------
-  const int pme = pgroup * 16 + frow, pyy = pme / W, pxx = pme - pyy * W;
+
+  // ---- 5. MFMAs: 16 output channels (rows of the weight fragments) x this workgroup's 16 pixels (columns) -----------------------------
+  const int pyy = pme / W, pxx_me = pme - pyy * W;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  if (sp.c9) {
-    const int dy = wave / 3, dx = wave - dy * 3;
-    const T* arow = s_a9 + ((pyy + dy) * PW + pxx + dx) * RS9 + fk * 8;
+  if constexpr (KS9 > 0) {
+    if (a.taps9 == 9) {
+      const int dy = wave / 3, dx = wave - dy * 3;
+      const T* arow = s_a9 + ((pyy + dy) * PW + pxx_me + dx) * RS9 + fk * 8;
 #pragma unroll
-    for (int k = 0; k < 16; ++k)
-      if (k < sp.ks9) Mfma<T>::run(wown[k], *reinterpret_cast<const uint4*>(arow + k * 32), acc);
+      for (int k = 0; k < KS9; ++k) Mfma<T>::run(wown[k], *reinterpret_cast<const uint4*>(arow + k * 32), acc);
+    }
   }
   {
-    const T* arow8 = s_a9 + ((pyy + 2) * PW + pxx + 2) * RS9 + fk * 8;
+    // tap 8 of a 9-tap segment sits at (+2, +2) of the padded map, the only tap of a GroupNorm'd 1-tap segment at the centre
+    const int sh = a.taps9 == 9 ? 2 : 1;
+    const T* arow8 = s_a9 + ((pyy + sh) * PW + pxx_me + sh) * RS9 + fk * 8;
     const T* arow1 = s_a1 + frow * RS1 + fk * 8;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int j = wave + 8 * k;
-      if (j < sp.pooled) {
-        const bool t8 = sp.c9 && j < sp.ks9;
-        const T* ap = t8 ? arow8 + j * 32 : arow1 + (j - (sp.c9 ? sp.ks9 : 0)) * 32;
+      if (j < a.pooled) {
+        const T* ap = (KS9 > 0 && j < KS9) ? arow8 + j * 32 : arow1 + (j - KS9) * 32;
         Mfma<T>::run(wpool[k], *reinterpret_cast<const uint4*>(ap), acc);
       }
     }
@@ -292,75 +374,103 @@ __global__ void __launch_bounds__(SM_NTHR) conv_small_kernel(const ConvParams p,
   __syncthreads();
   SSTAMP(6);
 
-  // ---- 6. sum of the 8 partial tiles + epilogue, by wave 0 ------------------------------------------------------------------
+  // ---- 6. sum of the 8 partial tiles + epilogue, by wave 0 (conv_epilogue4's arithmetic on the prefetched operands) -------------------
   if (wave == 0) {
-    f32x4 s = s_red[lane];
+    f32x4 pv[8];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) s += s_red[w * 64 + lane];
-    const int n = ntile * 16 + fk * 4;
-    const int64_t m = img + pme;
-    float v[4] = {s[0], s[1], s[2], s[3]};
-    const bool live = n < p.Cout;
-    if (live) conv_epilogue4<TO>(p, m, b, n, v);
-    if (p.stat_out) {
-      const int scpg = p.Cout / p.stat_G;
+    for (int w = 0; w < 8; ++w) pv[w] = s_red[w * 64 + lane];
+    f32x4 s = pv[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) s += pv[w];
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = (((s[r] + e_bias[r]) + e_tb[r]) + e_res[r]) * a.scale;
+    if (live) OutVec<TO>::store(out + (img + pme) * a.Cout + n_out, v);
+    if constexpr (sizeof(TO) == 2) {                               // statistics are those of the STORED tensor
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (float)(TO)v[r];
+    }
+    if (stat_out) {
+      const int scpg = a.Cout / stat_G;
       const float q1 = live ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
       const float q2 = live ? (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]) : 0.f;
       const float r1 = row16_sum(q1), r2 = row16_sum(q2);
       if (frow == 0 && live) {
-        // (4 consecutive channels = one unit when scpg == 4; larger groups: several lanes add into one slot)
-        atomicAdd(&s_ostat[((n - ntile * 16) / scpg) * 2], (double)r1);
-        atomicAdd(&s_ostat[((n - ntile * 16) / scpg) * 2 + 1], (double)r2);
+        atomicAdd(&s_ostat[((n_out - ntile * 16) / scpg) * 2], (double)r1);
+        atomicAdd(&s_ostat[((n_out - ntile * 16) / scpg) * 2 + 1], (double)r2);
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the LDS atomics of this wave have landed
-      const int g0 = (ntile * 16) / scpg;
-      const int ng = min(p.stat_G - g0, (16 + scpg - 1) / scpg);
+      const int g_0 = (ntile * 16) / scpg;
+      const int ng = min(stat_G - g_0, (16 + scpg - 1) / scpg);
       if (lane < ng * 2) {
-        const int k = lane & 1, g = g0 + (lane >> 1);
-        atomicAdd(p.stat_out + (((int64_t)b * p.stat_nsplit + pgroup % p.stat_nsplit) * p.stat_G + g) * 2 + k, s_ostat[(g - g0) * 2 + k]);
+        const int k = lane & 1, g = g_0 + (lane >> 1);
+        atomicAdd(stat_out + (((int64_t)b * stat_nsplit + pgroup % stat_nsplit) * stat_G + g) * 2 + k, s_ostat[(g - g_0) * 2 + k]);
       }
     }
     SSTAMP(7);
   }
 }
 
-template <typename T, typename TO>
-static int launch_small(const ConvParams& p, const SmallPlan& sp, hipStream_t st) {
-  const bool gnp = p.gn_sums != nullptr;
-  auto kern = gnp ? &conv_small_kernel<T, TO, true> : &conv_small_kernel<T, TO, false>;
-  static bool attr[2] = {false, false};
-  if (!attr[gnp]) {
+template <typename T, typename TO, bool GNP, int KS9, int NRAW>
+static int launch_small_i(const ConvParams& p, const SmallArgs& a, int lds, hipStream_t st) {
+  auto kern = &conv_small_kernel<T, TO, GNP, KS9, NRAW>;
+  static bool attr = false;
+  if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (e != hipSuccess) {
       fdbm_set_error("fdbm_conv_igemm(small): hipFuncSetAttribute failed: %s", hipGetErrorString(e));
       return 2;
     }
-    attr[gnp] = true;
+    attr = true;
   }
   dim3 grid((unsigned)((p.Cout + 15) / 16), (unsigned)(p.H * p.W / 16), (unsigned)p.B);
-  kern<<<grid, SM_NTHR, sp.lds_bytes, st>>>(p, sp);
+  kern<<<grid, SM_NTHR, lds, st>>>(a, reinterpret_cast<TO*>(p.out), p.stat_out, p.stat_G, p.stat_nsplit);
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm(small)");
   return 0;
+}
+
+template <typename T, typename TO, bool GNP, int KS9>
+static int launch_small_n(const ConvParams& p, const SmallArgs& a, int lds, hipStream_t st) {
+  if constexpr (KS9 == 0) {
+    return launch_small_i<T, TO, GNP, 0, 1>(p, a, lds, st);
+  } else {
+    const int items = a.HW * (a.c9 / 8);
+    const int nraw = (items + SM_NTHR - 1) / SM_NTHR;
+    if (nraw <= 1) return launch_small_i<T, TO, GNP, KS9, 1>(p, a, lds, st);
+    if (nraw <= 2) return launch_small_i<T, TO, GNP, KS9, 2>(p, a, lds, st);
+    if (nraw <= 4) return launch_small_i<T, TO, GNP, KS9, 4>(p, a, lds, st);
+    return launch_small_i<T, TO, GNP, KS9, 8>(p, a, lds, st);
+  }
+}
+
+template <typename T, typename TO>
+static int launch_small(const ConvParams& p, const SmallArgs& a, int lds, hipStream_t st) {
+  const bool gnp = p.gn_sums != nullptr;
+  if (a.c9 == 0) return launch_small_n<T, TO, false, 0>(p, a, lds, st);
+  if (a.c9 == 256) return gnp ? launch_small_n<T, TO, true, 8>(p, a, lds, st) : launch_small_n<T, TO, false, 8>(p, a, lds, st);
+  return gnp ? launch_small_n<T, TO, true, 16>(p, a, lds, st) : launch_small_n<T, TO, false, 16>(p, a, lds, st);
 }
 
 }  // namespace
 
 // can this convolution run on the whole-map kernel?  (16-bit tensors; p filled by fdbm_conv_igemm, p.w = fragment-major weights)
 bool fdbm_conv_small_ok(const ConvParams& p) {
-  SmallPlan sp;
-  return small_plan(p, &sp);
+  SmallArgs a;
+  int lds;
+  return small_plan(p, &a, &lds);
 }
 
 int fdbm_launch_conv_small(const ConvParams& p, int dt_in, int dt_out, hipStream_t st) {
-  SmallPlan sp;
-  if (!small_plan(p, &sp)) {
+  SmallArgs a;
+  int lds;
+  if (!small_plan(p, &a, &lds)) {
     fdbm_set_error("fdbm_conv_igemm(small): shape not supported");
     return 1;
   }
-  if (dt_in == FDBM_BF16 && dt_out == FDBM_BF16) return launch_small<bf16_t, bf16_t>(p, sp, st);
-  if (dt_in == FDBM_BF16 && dt_out == FDBM_F32) return launch_small<bf16_t, float>(p, sp, st);
-  if (dt_in == FDBM_F16 && dt_out == FDBM_F16) return launch_small<f16_t, f16_t>(p, sp, st);
-  if (dt_in == FDBM_F16 && dt_out == FDBM_F32) return launch_small<f16_t, float>(p, sp, st);
+  if (dt_in == FDBM_BF16 && dt_out == FDBM_BF16) return launch_small<bf16_t, bf16_t>(p, a, lds, st);
+  if (dt_in == FDBM_BF16 && dt_out == FDBM_F32) return launch_small<bf16_t, float>(p, a, lds, st);
+  if (dt_in == FDBM_F16 && dt_out == FDBM_F16) return launch_small<f16_t, f16_t>(p, a, lds, st);
+  if (dt_in == FDBM_F16 && dt_out == FDBM_F32) return launch_small<f16_t, float>(p, a, lds, st);
   fdbm_set_error("fdbm_conv_igemm(small): 16-bit tensors only");
   return 1;
 }

@@ -604,8 +604,8 @@ def test_conv_full_size_linearity(dtype):
 @pytest.mark.parametrize("splitk", [False, True], ids=["direct", "splitk"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, F32S])
 @pytest.mark.parametrize("HW", [4, 8, 16], ids=["4x4", "8x8", "16x16"])
-@pytest.mark.parametrize("cin,cin1", [(64, 0), (128, 0), (192, 64), (320, 0), (384, 192), (448, 64), (576, 0)],
-                         ids=["1", "2", "3+1", "5", "6+3", "7+1", "9"])
+@pytest.mark.parametrize("cin,cin1", [(64, 0), (128, 0), (192, 64), (256, 0), (256, 256), (320, 0), (384, 192), (448, 64), (512, 512), (576, 0)],
+                         ids=["1", "2", "3+1", "4", "4+4", "5", "6+3", "7+1", "8+8", "9"])
 def test_conv_tap_chunk_remainders(cin, cin1, HW, dtype, splitk, policy):
     """The wave-per-tap kernel keeps 4 register sets of 64-channel chunks in flight on its one-n-tile tiles (groups
     of 4 chunks unrolled, then a 1..3 chunk tail; a load cursor that stops on the workgroup's last chunk): every
@@ -632,7 +632,7 @@ def test_conv_tap_chunk_remainders(cin, cin1, HW, dtype, splitk, policy):
     finally:
         hip.conv_policy(old)
     # policy 43 (the default): the whole-map kernel takes the 16-bit cases whose map and channel counts it accepts
-    small_ok = policy == 43 and dtype == torch.bfloat16 and HW <= 8 and cin in (64, 128, 256, 512) and cin1 % 64 == 0
+    small_ok = policy == 43 and dtype == torch.bfloat16 and HW <= 8 and cin in (256, 512) and cin1 % 64 == 0
     assert kind == (6 if small_ok else 2), (kind, small_ok)
     err = (out - ref).abs().max().item()
     assert err < (2e-5 if dtype == torch.float32 else 2e-2), err

@@ -751,7 +751,7 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     if (!(fth && fth[0] == '1') && (!a->gn_sums && !gn_units ? true : a->gn_C <= 256)) th = 8;
     return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
   }
-  if (kind == 2 && (conv_policy() & 32) && a->dt_in != FDBM_F32) {
+  if (kind == 2 && (conv_policy() & 32) && a->dt_in != FDBM_F32 && a->dt_out == a->dt_in) {
     // the smallest maps (4 x 4, 8 x 8 at batch 1): whole map per workgroup, GroupNorm statistics by the consumer (conv_small.hip)
     ConvParams ps = p;
     ps.w = a->w_frag;

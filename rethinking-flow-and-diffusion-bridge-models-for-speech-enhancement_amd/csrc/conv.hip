@@ -560,7 +560,7 @@ bool fdbm_conv_ring_ok(const ConvParams& p, int rows);
 int fdbm_launch_conv_ring8(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                 // conv_ring8.hip
 int fdbm_launch_conv_head(const ConvParams& p, int dt_in, hipStream_t st);                               // conv_head.hip
 int fdbm_launch_conv_small(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                  // conv_small.hip
-bool fdbm_conv_small_ok(const ConvParams& p);
+bool fdbm_conv_small_ok(const ConvParams& p, bool f32_out);
 bool fdbm_conv_head_ok(const ConvParams& p);
 
 // Which kernel runs a conv of this shape: kind 1 = halo-patch 3x3 kernel (conv_patch.hip, tile
@@ -751,13 +751,13 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     if (!(fth && fth[0] == '1') && (!a->gn_sums && !gn_units ? true : a->gn_C <= 256)) th = 8;
     return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
   }
-  if (kind == 2 && (conv_policy() & 32) && a->dt_in != FDBM_F32 && a->dt_out == a->dt_in) {
+  if (kind == 2 && (conv_policy() & 32) && a->dt_in != FDBM_F32) {
     // the smallest maps (4 x 4, 8 x 8 at batch 1): whole map per workgroup, GroupNorm statistics by the consumer (conv_small.hip)
     ConvParams ps = p;
     ps.w = a->w_frag;
     ps.ksplit = 1;
     ps.partial = reinterpret_cast<float*>(a->acc_ws);          // (diagnostic stamps only)
-    if (fdbm_conv_small_ok(ps)) { g_last_kind = 6; return fdbm_launch_conv_small(ps, a->dt_in, a->dt_out, st); }
+    if (fdbm_conv_small_ok(ps, a->dt_out == FDBM_F32)) { g_last_kind = 6; return fdbm_launch_conv_small(ps, a->dt_in, a->dt_out, st); }
   }
   if (kind == 2) {
     p.w = a->w_frag;

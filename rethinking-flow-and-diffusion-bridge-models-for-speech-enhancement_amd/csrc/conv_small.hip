@@ -82,6 +82,10 @@ struct SmallArgs {
   const float* tbias;
   int tb_stride;
   const void* res;
+  const float* res_lo;                // residual at half resolution (f32 [B][H/2][W/2][Cout]), upsampled 2x in the epilogue
+  const float* comb_pyr;              // Combine('sum'): out += comb_b[n] + comb_w[n][0..3] . comb_pyr[m][0..3]
+  const float* comb_w;
+  const float* comb_b;
   float scale;
   int Cout;
   unsigned long long* stamps;
@@ -175,7 +179,7 @@ static bool small_plan(const ConvParams& p, SmallArgs* out, int* lds_bytes, int*
       }
     }
   }
-  if (p.res_lo || p.comb_pyr) return false;                        // (upsampled residual / Combine epilogues stay on the general kernels)
+  a.res_lo = p.res_lo; a.comb_pyr = p.comb_pyr; a.comb_w = p.comb_w; a.comb_b = p.comb_b;
   a.a9_bytes = a.c9 ? (a.band ? a.rpw + 2 : p.H + 2) * (p.W + 2) * (a.c9 + 8) * 2 : 0;
   a.a1_bytes = a.c1 ? 16 * mt * (a.c1 + 8) * 2 : 0;
   *lds_bytes = a.a9_bytes + a.a1_bytes + 8 * mt * 64 * 16 /*partials*/ + SM_NTHR * 16 /*stat partials*/ + 64 * 8 * 2 /*out stats*/ + 64;
@@ -193,8 +197,8 @@ __device__ __forceinline__ uint4 ld16(const T* p) { return *reinterpret_cast<con
 // GNS: 0 no GroupNorm, 1 statistics by the workgroup (whole-map form), 2 from the producers' unit sums (band form).
 // KS9: staged channels / 32 (8 | 16; 0: no staged segment).  NRAW: staged 16-byte items per thread (1 | 2 | 4 | 8).
 // MT: 16-pixel MFMA column tiles per workgroup (1; 4 in the band form of the 32 x 32 level).
-template <typename T, int GNS, int KS9, int NRAW, int MT>
-__global__ void __launch_bounds__(SM_NTHR) conv_small_kernel(const SmallArgs a, T* __restrict__ out, double* __restrict__ stat_out,
+template <typename T, typename TO, int GNS, int KS9, int NRAW, int MT>
+__global__ void __launch_bounds__(SM_NTHR) conv_small_kernel(const SmallArgs a, TO* __restrict__ out, double* __restrict__ stat_out,
                                                              int stat_G, int stat_nsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr bool GNP = GNS != 0;
@@ -319,7 +323,7 @@ __global__ void __launch_bounds__(SM_NTHR) conv_small_kernel(const SmallArgs a, 
   const f32x4 e_bias = *reinterpret_cast<const f32x4*>(a.bias ? a.bias + n_ld : g_conv_zero);
   const f32x4 e_tb = *reinterpret_cast<const f32x4*>(a.tbias ? a.tbias + (int64_t)b * a.tb_stride + n_ld : g_conv_zero);
   float e_res[4];
-  OutVec<T>::load(a.res ? reinterpret_cast<const T*>(a.res) + (img + pme_e) * a.Cout + n_ld : reinterpret_cast<const T*>(g_conv_zero), e_res);
+  OutVec<TO>::load(a.res ? reinterpret_cast<const TO*>(a.res) + (img + pme_e) * a.Cout + n_ld : reinterpret_cast<const TO*>(g_conv_zero), e_res);
   SSTAMP(1);
 
   // ---- 2. zero the padded rows and the output statistics (LDS only) ------------------------------------------------------------
@@ -482,10 +486,46 @@ __global__ void __launch_bounds__(SM_NTHR) conv_small_kernel(const SmallArgs a, 
     for (int w = 1; w < 8; ++w) s += pv[w];
     float v[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (((s[r] + e_bias[r]) + e_tb[r]) + e_res[r]) * a.scale;
-    if (live) OutVec<T>::store(out + (img + pme_e) * a.Cout + n_out, v);
+    for (int r = 0; r < 4; ++r) v[r] = ((s[r] + e_bias[r]) + e_tb[r]) + e_res[r];
+    if (a.res_lo) {
+      // upsampled half-resolution residual (the pyramid heads; tap order and weights of conv_epilogue4 / resample2x_kernel).
+      // Loaded here, not with the other operands: a few launches per forward use it, every launch would carry its registers.
+      const int y = pme_e / W, x = pme_e - y * W, H2 = H >> 1, W2 = W >> 1, iy = y >> 1, ix = x >> 1;
+      const int ys0 = (y & 1) ? iy : iy - 1, xs0 = (x & 1) ? ix : ix - 1;
+      const float wy0 = (y & 1) ? 0.75f : 0.25f, wx0 = (x & 1) ? 0.75f : 0.25f;
+      f32x4 q[4];
+      float wq[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = (float)(T)v[r];             // statistics are those of the STORED tensor
+      for (int t = 0; t < 4; ++t) {
+        const int ay = ys0 + (t >> 1), ax = xs0 + (t & 1);
+        const bool in = ay >= 0 && ay < H2 && ax >= 0 && ax < W2;
+        wq[t] = in ? ((t >> 1) ? 1.0f - wy0 : wy0) * ((t & 1) ? 1.0f - wx0 : wx0) : 0.f;
+        q[t] = *reinterpret_cast<const f32x4*>(in ? a.res_lo + (((int64_t)b * H2 + ay) * W2 + ax) * a.Cout + n_ld : g_conv_zero);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float up = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) up += wq[t] * q[t][r];
+        v[r] += up;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] *= a.scale;
+    if (a.comb_pyr) {                                              // Combine('sum') with the input pyramid
+      const f32x4 cq = *reinterpret_cast<const f32x4*>(a.comb_pyr + (img + pme_e) * 4);
+      const f32x4 cb = *reinterpret_cast<const f32x4*>(a.comb_b + n_ld);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const f32x4 cw = *reinterpret_cast<const f32x4*>(a.comb_w + (int64_t)(n_ld + r) * 4);
+        v[r] += cb[r] + (((cw[0] * cq[0] + cw[1] * cq[1]) + cw[2] * cq[2]) + cw[3] * cq[3]);
+      }
+    }
+    if (live) OutVec<TO>::store(out + (img + pme_e) * a.Cout + n_out, v);
+    if constexpr (sizeof(TO) == 2) {                               // statistics are those of the STORED tensor
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (float)(TO)v[r];
+    }
     if (stat_out) {
       const int scpg = a.Cout / stat_G;
       const float q1 = live ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
@@ -513,9 +553,9 @@ __global__ void __launch_bounds__(SM_NTHR) conv_small_kernel(const SmallArgs a, 
   if (wave == 0) SSTAMP(7);
 }
 
-template <typename T, int GNS, int KS9, int NRAW, int MT>
+template <typename T, typename TO, int GNS, int KS9, int NRAW, int MT>
 static int launch_small_i(const ConvParams& p, const SmallArgs& a, int lds, hipStream_t st) {
-  auto kern = &conv_small_kernel<T, GNS, KS9, NRAW, MT>;
+  auto kern = &conv_small_kernel<T, TO, GNS, KS9, NRAW, MT>;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 155 * 1024);
@@ -526,62 +566,73 @@ static int launch_small_i(const ConvParams& p, const SmallArgs& a, int lds, hipS
     attr = true;
   }
   dim3 grid((unsigned)((p.Cout + 15) / 16), (unsigned)(p.H * p.W / (16 * MT)), (unsigned)p.B);
-  kern<<<grid, SM_NTHR, lds, st>>>(a, reinterpret_cast<T*>(p.out), p.stat_out, p.stat_G, p.stat_nsplit);
+  kern<<<grid, SM_NTHR, lds, st>>>(a, reinterpret_cast<TO*>(p.out), p.stat_out, p.stat_G, p.stat_nsplit);
   FDBM_LAUNCH_CHECK("fdbm_conv_igemm(small)");
   return 0;
 }
 
 // staged items per thread -> the instantiated NRAW
-template <typename T, int GNS, int KS9, int MT>
+template <typename T, typename TO, int GNS, int KS9, int MT>
 static int launch_small_n(const ConvParams& p, const SmallArgs& a, int lds, hipStream_t st) {
   if constexpr (KS9 == 0) {
-    return launch_small_i<T, 0, 0, 1, MT>(p, a, lds, st);
+    return launch_small_i<T, TO, 0, 0, 1, MT>(p, a, lds, st);
   } else {
     const int items = (a.band ? (a.rpw + 2) * a.W : a.HW) * (a.c9 / 8);
     const int nraw = (items + SM_NTHR - 1) / SM_NTHR;
     if constexpr (MT == 1 && GNS != 2) {
       if (!a.band) {
-        if (nraw <= 1) return launch_small_i<T, GNS, KS9, 1, 1>(p, a, lds, st);
-        if (nraw <= 2) return launch_small_i<T, GNS, KS9, 2, 1>(p, a, lds, st);
+        if (nraw <= 1) return launch_small_i<T, TO, GNS, KS9, 1, 1>(p, a, lds, st);
+        if (nraw <= 2) return launch_small_i<T, TO, GNS, KS9, 2, 1>(p, a, lds, st);
       }
     }
-    if (nraw <= 4) return launch_small_i<T, GNS, KS9, 4, MT>(p, a, lds, st);
-    return launch_small_i<T, GNS, KS9, 8, MT>(p, a, lds, st);
+    if (nraw <= 4) return launch_small_i<T, TO, GNS, KS9, 4, MT>(p, a, lds, st);
+    return launch_small_i<T, TO, GNS, KS9, 8, MT>(p, a, lds, st);
   }
 }
 
 template <typename T>
 static int launch_small(const ConvParams& p, const SmallArgs& a, int lds, int mt, hipStream_t st) {
   const bool gnp = p.gn_sums != nullptr;
-  if (a.c9 == 0) return launch_small_n<T, 0, 0, 1>(p, a, lds, st);
+  if (a.c9 == 0) return launch_small_n<T, T, 0, 0, 1>(p, a, lds, st);
   if (mt == 4) {            // band form, four column tiles (32 x 32 level): 256 staged channels only (plan)
-    return gnp ? launch_small_n<T, 2, 8, 4>(p, a, lds, st) : launch_small_n<T, 0, 8, 4>(p, a, lds, st);
+    return gnp ? launch_small_n<T, T, 2, 8, 4>(p, a, lds, st) : launch_small_n<T, T, 0, 8, 4>(p, a, lds, st);
   }
   if (a.band) {
-    if (a.c9 == 256) return gnp ? launch_small_n<T, 2, 8, 1>(p, a, lds, st) : launch_small_n<T, 0, 8, 1>(p, a, lds, st);
-    return gnp ? launch_small_n<T, 2, 16, 1>(p, a, lds, st) : launch_small_n<T, 0, 16, 1>(p, a, lds, st);
+    if (a.c9 == 256) return gnp ? launch_small_n<T, T, 2, 8, 1>(p, a, lds, st) : launch_small_n<T, T, 0, 8, 1>(p, a, lds, st);
+    return gnp ? launch_small_n<T, T, 2, 16, 1>(p, a, lds, st) : launch_small_n<T, T, 0, 16, 1>(p, a, lds, st);
   }
-  if (a.c9 == 256) return gnp ? launch_small_n<T, 1, 8, 1>(p, a, lds, st) : launch_small_n<T, 0, 8, 1>(p, a, lds, st);
-  return gnp ? launch_small_n<T, 1, 16, 1>(p, a, lds, st) : launch_small_n<T, 0, 16, 1>(p, a, lds, st);
+  if (a.c9 == 256) return gnp ? launch_small_n<T, T, 1, 8, 1>(p, a, lds, st) : launch_small_n<T, T, 0, 8, 1>(p, a, lds, st);
+  return gnp ? launch_small_n<T, T, 1, 16, 1>(p, a, lds, st) : launch_small_n<T, T, 0, 16, 1>(p, a, lds, st);
+}
+
+// f32 output (the 4-channel pyramid heads): GroupNorm'd 256-channel sources only
+template <typename T>
+static int launch_small_f32(const ConvParams& p, const SmallArgs& a, int lds, int mt, hipStream_t st) {
+  if (mt == 4) return launch_small_n<T, float, 2, 8, 4>(p, a, lds, st);
+  if (a.band) return launch_small_n<T, float, 2, 8, 1>(p, a, lds, st);
+  return launch_small_n<T, float, 1, 8, 1>(p, a, lds, st);
 }
 
 }  // namespace
 
 // can this convolution run on the whole-map / band kernel?  (16-bit tensors, output of the input's type; p filled by
 // fdbm_conv_igemm, p.w = fragment-major weights)
-bool fdbm_conv_small_ok(const ConvParams& p) {
+bool fdbm_conv_small_ok(const ConvParams& p, bool f32_out) {
   SmallArgs a;
   int lds, mt;
-  return small_plan(p, &a, &lds, &mt);
+  if (!small_plan(p, &a, &lds, &mt)) return false;
+  return !f32_out || (p.gn_sums != nullptr && a.c9 == 256 && a.taps9 == 9);
 }
 
 int fdbm_launch_conv_small(const ConvParams& p, int dt_in, int dt_out, hipStream_t st) {
   SmallArgs a;
   int lds, mt;
-  if (!small_plan(p, &a, &lds, &mt) || dt_in != dt_out) {
+  if (!small_plan(p, &a, &lds, &mt) || !fdbm_conv_small_ok(p, dt_out == FDBM_F32)) {
     fdbm_set_error("fdbm_conv_igemm(small): shape not supported");
     return 1;
   }
+  if (dt_in == FDBM_BF16 && dt_out == FDBM_F32) return launch_small_f32<bf16_t>(p, a, lds, mt, st);
+  if (dt_in == FDBM_F16 && dt_out == FDBM_F32) return launch_small_f32<f16_t>(p, a, lds, mt, st);
   if (dt_in == FDBM_BF16) return launch_small<bf16_t>(p, a, lds, mt, st);
   if (dt_in == FDBM_F16) return launch_small<f16_t>(p, a, lds, mt, st);
   fdbm_set_error("fdbm_conv_igemm(small): 16-bit tensors only");

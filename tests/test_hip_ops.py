@@ -652,6 +652,12 @@ FUSED_CASES = [
     ("tap_gn_8_b2", 2, 8, 8, [128], 256, 32, 32, False, True),
     ("straddle_384", 1, 16, 16, [256, 128], 128, 32, 32, True, False),        # groups of 12 across 256 | 128
     ("straddle_384_big", 1, 128, 128, [256, 128], 128, 32, 32, True, False),
+    # the whole-map / band kernel's shapes (conv_small.hip: 256 | 512 staged channels) incl. its Combine epilogue
+    ("small_comb_8", 2, 8, 8, [256], 256, 32, 32, False, True),
+    ("small_cat_4", 2, 4, 4, [256, 256], 256, 32, 32, True, False),
+    ("band_comb_16", 1, 16, 16, [256], 256, 32, 32, False, True),
+    ("band_cat_16", 2, 16, 16, [256, 256], 256, 32, 32, True, False),
+    ("band_32", 1, 32, 32, [256], 256, 32, 32, False, True),
 ]
 
 
@@ -705,6 +711,36 @@ def test_conv_fused_gn_combine_stats(case, dtype, splitk, conv_kernels, units):
     og = out.reshape(B, G_out, -1)                         # stats of what was stored
     ref_st = torch.stack([og.sum(-1), (og * og).sum(-1)], -1)
     assert ((st - ref_st).abs() <= 1e-4 * (1 + ref_st.abs()) * (10 if dtype == torch.bfloat16 else 1)).all(), name
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("S", [4, 8, 16, 32])
+def test_conv_small_pyramid_head(S, dtype):
+    """The 4-channel f32 pyramid heads of the small levels on the whole-map / band kernel (conv_small.hip): GroupNorm + SiLU
+    prologue (unit statistics), conv3x3(256 -> 4), the half-resolution pyramid upsampled into the epilogue, f32 output
+    (ncsnpp_v2.py:372-389).  The kernel must be the one that ran (kind 6), against torch and against the wave-per-tap
+    kernel on the same inputs."""
+    B, C, cout = 2, 256, 4
+    x = rnd(B, C, S, S, seed=S) * 1.3 + 0.1
+    q = lambda t: t.to(dtype).float()
+    gamma, beta = rnd(C, seed=3) * 0.1 + 1, rnd(C, seed=4) * 0.1
+    w = rnd(cout, C, 3, 3, seed=20) / math.sqrt(C * 9)
+    bias = rnd(cout, seed=30) * 0.1
+    r = rnd(B, cout, S // 2, S // 2, seed=72)
+    act = F.silu(F.group_norm(q(x), 32, gamma, beta, eps=1e-6)).to(dtype).float()
+    ref = F.conv2d(act, q(w), bias, padding=1) + onet.upsample_2d(r)
+    outs = {}
+    for pol in (43, 11):
+        old = hip.conv_policy(pol)
+        try:
+            outs[pol], _, _ = run_conv([(x, 9)], [w], bias, dtype, out_dtype=torch.float32, res_up=r, scale=1.0,
+                                       gn=(32, gamma, beta, True, 1, True))
+            kind = hip.lib().fdbm_conv_last_kind()
+        finally:
+            hip.conv_policy(old)
+        assert kind == (6 if pol == 43 else 2), (pol, kind)
+        assert (outs[pol] - ref).abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 4e-3), (pol, S)
+    assert (outs[43] - outs[11]).abs().max().item() < 5e-3
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])

@@ -403,7 +403,7 @@ def test_ode_int_vs_reference_golden(golden, path, tol, tag, split):
     The accept / reject decisions sit on error norms near 1, so rounding-level differences between the two networks'
     evaluations move single decisions (sb at 1e-3: 7 rejected steps) and with them the step sequence: the evaluation
     count agrees to 15 %, and the final states agree to what two valid runs of an adaptive solver at that tolerance
-    agree to - 5 x tol absolute (|x| <= 0.14) - i.e. 5e-5 at the default tolerance."""
+    agree to - 5 x tol absolute (|x| <= 0.14), i.e. 5e-5 at the default tolerance - for fm; sb: see the bound below."""
     g = golden("ode_int_5M")
     hp = VARIANTS["ncsnpp_v2_5M"]
     sd = fill_state_dict(Spec(**hp).param_shapes(), seed=0, profile="contractive")
@@ -415,7 +415,14 @@ def test_ode_int_vs_reference_golden(golden, path, tol, tag, split):
     nref = int(g[f"{path}_nfev{tag}"])
     assert abs(br.last_ode_stats["nfev"] - nref) <= 0.15 * nref, (br.last_ode_stats, nref)
     err = (out - ref).abs().max().item()
-    assert err <= 5 * tol, (path, tol, err, br.last_ode_stats, nref)
+    # fm: 5 x tol.  sb: the probability-flow ODE of the Schroedinger bridge is singular at its start (t = T: weights of
+    # 1e7 that cancel between x and y), and the integration amplifies a perturbation of the network output ~5 000 x -
+    # measured on the CPU: 1e-5 RELATIVE noise on the oracle network's output moves the final state by 5.5e-2, while the
+    # same integrator code with the unperturbed oracle reproduces the reference bit for bit
+    # (tests/test_host_api.py::test_ode_int_with_oracle_network_is_the_reference).  The HIP network differs from the
+    # reference's by ~1e-5 absolute per evaluation: bound 2e-2 (measured 5e-3 at either tolerance).
+    bound = 5 * tol if path == "fm" else 2e-2
+    assert err <= bound, (path, tol, err, br.last_ode_stats, nref)
 
 
 @pytest.mark.parametrize("name", ["tfgridnet_5l32c100", "tfgridnet_4l32c80"])

@@ -384,3 +384,24 @@ def test_philox_restatement_known_answers():
     z = rng.complex_normal(200000, 1, 12345)
     assert abs(z.real.mean()) < 5e-3 and abs(z.real.var() - 0.5) < 5e-3 and abs(z.imag.var() - 0.5) < 5e-3
     assert np.array_equal(rng.complex_normal(16, 1, 12345, first=100), z[100:116])       # element-addressable
+
+
+def test_ode_int_with_oracle_network_is_the_reference(golden):
+    """`Bridge.ode_sampler_int` (the SciPy route, host tensors) driven by the CPU oracle network reproduces the REFERENCE's
+    own run of fdbm/bridge.py:115-140 (fixture ode_int_5M: ncsnpp_v2_5M, contractive filler, sb/bb, rtol = atol = 1e-3)
+    bit for bit, with the same number of network evaluations: the flow, the prior and the solver call are the reference's.
+    (What the GPU test can hold for this ill-conditioned integration is then a matter of the network's rounding alone.)"""
+    import torch
+    import fdbm_amd
+    from fdbm_amd.arch import Spec, VARIANTS
+    from fdbm_amd.weights import fill_state_dict
+    from oracle import ncsnpp as onet
+    g = golden("ode_int_5M")
+    hp = VARIANTS["ncsnpp_v2_5M"]
+    model = onet.Model(fill_state_dict(Spec(**hp).param_shapes(), seed=0, profile="contractive"), hp)
+    y = torch.from_numpy(g["y"])
+    torch.set_num_threads(8)
+    br = fdbm_amd.Bridge("sb", N=5, sampler_type="ode_int")
+    out = br.sampler(model, y, generator=torch.Generator().manual_seed(11), rtol=1e-3, atol=1e-3)
+    assert br.last_ode_stats["nfev"] == int(g["sb_nfev"])
+    assert torch.equal(torch.view_as_real(out), torch.view_as_real(torch.from_numpy(g["sb_ode_int"])))

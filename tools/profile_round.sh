@@ -30,6 +30,13 @@ for B in ${@:-1 64}; do
   # raw traces are large: keep the summaries only
   rm -rf $O/stats_b$B $O/fetch_b$B $O/write_b$B $O/sq_b$B
 done
+# the split-precision parity mode (f32 tensors, three f16 MFMAs per product) at batch 1: kernel stats of its bench line
+if [ -n "$F32S" ]; then
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f32s -- python3 bench.py --dtype f32s --batch 1 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $O/bench_b1_f32s_under_rocprof.json 2> $O/stats_f32s.err
+  cp "$(find $O/stats_f32s -name '*kernel_stats.csv' | head -1)" $O/kernel_stats_b1_f32s.csv
+  rm -rf $O/stats_f32s
+  echo "f32s done"
+fi
 # BASELINE configs[4] (fp16 storage, batch 16, N = 100): kernel stats of the stochastic and the predictor-corrector sampler
 if [ -n "$CONFIG4" ]; then
   for S in sde_ei pc; do

@@ -155,6 +155,10 @@ static bool small_plan(const ConvParams& p, SmallArgs* out, int* lds_bytes, int*
     if (a.c9 && (a.rpw + 2) * p.W * (a.c9 / 8) > 8 * SM_NTHR) return false;
     if (mt == 4 && a.c9 != 256) return false;                      // (the four-tile form is instantiated for 256 staged channels)
   }
+  // a latency kernel: every workgroup re-reads its 16 output channels' weights and re-stages the rows it needs, which only pays
+  // while the launch is a few hundred workgroups (batch 1: every level up to 32 x 32; batch 64: the 4 x 4 level) - beyond
+  // that the wave-per-tap kernel's wider tiles win (batch 64: 3.4 ms per forward on this kernel against 0.9 ms)
+  if ((int64_t)((p.Cout + 15) / 16) * (a.HW / (16 * mt)) * p.B > 512) return false;
   *mt_out = mt;
   a.ks1 = a.c1 / 32;
   a.pooled = (a.c9 ? a.c9 / 32 : 0) + a.ks1;                       // tap 8 (or the centre tap) of the staged channels + the raw ones

@@ -72,7 +72,7 @@ class SamplerGraph:
                      p(prog.dense_out) if nxt else 0, p(self.dense_tab[i_next * B]) if nxt else 0, B * R if nxt else 0,
                      B, F, ba["Fn"], T)
 
-        if os.environ.get("FDBM_STEP_BOUNDARY", "1") == "0":          # A/B (tools/step_ab.py): the five separate launches per step
+        if os.environ.get("FDBM_STEP_BOUNDARY", "1") == "0":          # A/B (tools/ab.py step): the five separate launches per step
             n = prog.x_in[0].numel()
             for i in range(self.N):
                 hip.call("fdbm_copy_f32", p(prog.dense_out), p(self.dense_tab[i * B]), B * R)

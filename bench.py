@@ -438,7 +438,7 @@ def main():
     achieved = f_dom / t_dom / 1e12
     traffic = None
     fam_name = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel", 3: "conv_ring_kernel<R=16>",
-                4: "conv_ring_kernel<R=8>", 5: "conv_head_kernel", 6: "conv_small_kernel"}
+                4: "conv_ring_kernel<R=8>", 5: "conv_head_kernel", 6: "conv_small_kernel", 7: "conv_mid_kernel"}
     pmc_tab, pmc_src = {}, None
     for rnd in ("r03", "r02"):          # the newest committed PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over this command)
         cand = os.path.join(ROOT, "profiles", rnd, f"pmc_traffic_b{args.batch}_bf16.json")

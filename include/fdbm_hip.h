@@ -323,8 +323,8 @@ int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int first_taps, int
 int fdbm_conv_policy(int mask);
 /* kernel family of the most recent fdbm_conv_igemm launch of this process: 0 tap-outer implicit GEMM,
  * 1 halo-patch, 2 wave-per-tap, 3 ring (16 x 16 pixel tiles), 4 ring (8 x 16 pixel tiles), 5 head (<= 16 f32 output
- * channels, weights resident in LDS); -1 before the first
- * call (for measurement harnesses) */
+ * channels, weights resident in LDS), 6 whole-map / band kernel of the <= 32 x 32 maps, 7 64-channel-block kernel of the
+ * 64 x 64 level; -1 before the first call (for measurement harnesses) */
 int fdbm_conv_last_kind(void);
 
 /* Combine('sum'): out = conv1x1(4->C)(pyr) + h (layerspp.py:52-57; ncsnpp_v2.py:302-305).

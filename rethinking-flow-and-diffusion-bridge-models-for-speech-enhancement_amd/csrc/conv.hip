@@ -561,6 +561,8 @@ int fdbm_launch_conv_ring8(const ConvParams& p, int dt_in, int dt_out, hipStream
 int fdbm_launch_conv_head(const ConvParams& p, int dt_in, hipStream_t st);                               // conv_head.hip
 int fdbm_launch_conv_small(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                  // conv_small.hip
 bool fdbm_conv_small_ok(const ConvParams& p, bool f32_out);
+int fdbm_launch_conv_mid(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                    // conv_mid.hip
+bool fdbm_conv_mid_ok(const ConvParams& p);
 bool fdbm_conv_head_ok(const ConvParams& p);
 
 // Which kernel runs a conv of this shape: kind 1 = halo-patch 3x3 kernel (conv_patch.hip, tile
@@ -758,6 +760,9 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     ps.ksplit = 1;
     ps.partial = reinterpret_cast<float*>(a->acc_ws);          // (diagnostic stamps only)
     if (fdbm_conv_small_ok(ps, a->dt_out == FDBM_F32)) { g_last_kind = 6; return fdbm_launch_conv_small(ps, a->dt_in, a->dt_out, st); }
+    // the 64 x 64 level at batch 1: the wave-per-tap kernel's 4 x 16 pixel x 64 channel tile with that launch body (conv_mid.hip)
+    static const char* moff = getenv("FDBM_CONV_MID");          // experiments: "0" = the wave-per-tap kernel
+    if (!(moff && moff[0] == '0') && a->dt_out == a->dt_in && fdbm_conv_mid_ok(ps)) { g_last_kind = 7; return fdbm_launch_conv_mid(ps, a->dt_in, a->dt_out, st); }
   }
   if (kind == 2) {
     p.w = a->w_frag;

@@ -743,6 +743,69 @@ def test_conv_small_pyramid_head(S, dtype):
     assert (outs[43] - outs[11]).abs().max().item() < 5e-3
 
 
+MID_CASES = [
+    # name, B, H, W, 9-tap sources (a torch.cat under one GroupNorm), 1-tap sources (raw), Cout, GroupNorm
+    ("c256", 1, 64, 64, [256], [], 256, True),
+    ("c256_plain", 1, 64, 64, [256], [], 256, False),
+    ("cat512", 1, 64, 64, [256, 256], [], 256, True),
+    ("cat384", 1, 64, 64, [256, 128], [], 256, True),              # groups of 12 channels across the two sources
+    ("c128_256", 1, 64, 64, [128], [], 256, True),
+    ("sc512", 1, 64, 64, [256], [256, 256], 256, True),
+    ("sc384", 1, 64, 64, [256], [256, 128], 256, True),
+    ("sc128_cout128_b2", 2, 64, 64, [128], [128], 128, True),
+    ("b2_32x64", 2, 32, 64, [256], [128], 256, True),
+    ("b6_16x32_edges", 6, 16, 32, [256, 256], [], 256, True),       # every tile touches an image border
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", MID_CASES, ids=[c[0] for c in MID_CASES])
+def test_conv_mid_level64(case, dtype):
+    """The 64-channel-block kernel of the 64 x 64 level (conv_mid.hip, kind 7): conv3x3(silu(GroupNorm(cat(xs)))) [+ 1x1
+    shortcut of raw tensors] + bias + time bias + residual, scaled, with the unit statistics of the stored output
+    (layerspp.py:242-274), against torch and against the wave-per-tap kernel on the same inputs; the kernel must be the
+    one that ran."""
+    name, B, H, W, c9, c1, cout, gn = case
+    q = lambda t: t.to(dtype).float()
+    xs = [rnd(B, c, H, W, seed=10 + i) * (1.4 if i == 0 else 0.6) + 0.3 * i for i, c in enumerate(c9)]
+    x1 = [rnd(B, c, H, W, seed=40 + i) for i, c in enumerate(c1)]
+    Cg = sum(c9)
+    gamma, beta = rnd(Cg, seed=3) * 0.1 + 1, rnd(Cg, seed=4) * 0.1
+    w = rnd(cout, Cg, 3, 3, seed=20) / math.sqrt(Cg * 9)
+    bias, tb = rnd(cout, seed=30) * 0.1, rnd(B, cout, seed=31) * 0.2
+    res = rnd(B, cout, H, W, seed=32)
+    xcat = torch.cat([q(x) for x in xs], 1)
+    act = (F.silu(F.group_norm(xcat, 32, gamma, beta, eps=1e-6)) if gn else xcat).to(dtype).float()
+    ref = F.conv2d(act, q(w), bias, padding=1)
+    segs, weights, off = [(x, 9) for x in xs], [], 0
+    for c in c9:
+        weights.append(w[:, off:off + c]); off += c
+    for i, (x, c) in enumerate(zip(x1, c1)):
+        sw = rnd(cout, c, 1, 1, seed=50 + i) / math.sqrt(sum(c1))
+        ref = ref + F.conv2d(q(x), q(sw))
+        segs.append((x, 1)); weights.append(sw)
+    sc = 1 / math.sqrt(2.0)
+    ref = (ref + tb[:, :, None, None] + q(res)) * sc
+    kw = dict(tbias=tb, res=res, scale=sc, stat_G=cout // 4)
+    if gn:
+        kw["gn"] = (32, gamma, beta, True, len(c9), True)
+    outs, stats = {}, {}
+    for pol in (43, 11):
+        old = hip.conv_policy(pol)
+        try:
+            outs[pol], _, stats[pol] = run_conv(segs, weights, bias, dtype, splitk=True, **kw)
+            kind = hip.lib().fdbm_conv_last_kind()
+        finally:
+            hip.conv_policy(old)
+        assert kind == (7 if pol == 43 else 2), (pol, kind)
+        tol = 3e-2 if dtype == torch.bfloat16 else 4e-3
+        assert close(outs[pol], ref, tol), (name, pol, float((outs[pol] - ref).abs().max()))
+        og = outs[pol].reshape(B, cout // 4, -1)
+        ref_st = torch.stack([og.sum(-1), (og * og).sum(-1)], -1)
+        assert ((stats[pol] - ref_st).abs() <= 1e-3 * (1 + ref_st.abs())).all(), (name, pol)
+    assert (outs[43] - outs[11]).abs().max().item() < (3e-2 if dtype == torch.bfloat16 else 4e-3)
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
 @pytest.mark.parametrize("N,C", [(64, 32), (256, 256), (40, 96), (16, 192), (64, 64), (128, 192), (512, 256)])
 def test_attention(dtype, tol, N, C):

@@ -3,7 +3,7 @@
 With the third argument every conv family also carries its algorithmic bytes per launch and the ratio measured / algorithmic
 (the wasted-traffic factor)."""
 import csv, glob, json, sys, collections
-FAMILIES = ("conv_ring_kernel", "conv_head_kernel", "conv_patch_kernel", "conv_tap_kernel", "conv_small_kernel", "conv_igemm_kernel", "conv_stem_mfma_kernel",
+FAMILIES = ("conv_ring_kernel", "conv_head_kernel", "conv_patch_kernel", "conv_tap_kernel", "conv_small_kernel", "conv_mid_kernel", "conv_igemm_kernel", "conv_stem_mfma_kernel",
             "attention_mfma_kernel", "resample2x_tile_kernel", "resample2x_quad_kernel", "resample2x_kernel", "gn_stats_kernel", "gn_apply_kernel")
 out = {}
 for name, d in (("FETCH_SIZE", sys.argv[1]), ("WRITE_SIZE", sys.argv[2])):

@@ -20,7 +20,7 @@ for _ in range(4 if B < 16 else 2):
 torch.cuda.synchronize()
 print("ok", float(prog.s_out.abs().max()))
 if len(sys.argv) > 2:
-    FAM = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel", 3: "conv_ring_kernel<R=16>", 4: "conv_ring_kernel<R=8>", 5: "conv_head_kernel", 6: "conv_small_kernel"}
+    FAM = {0: "conv_igemm_kernel", 1: "conv_patch_kernel", 2: "conv_tap_kernel", 3: "conv_ring_kernel<R=16>", 4: "conv_ring_kernel<R=8>", 5: "conv_head_kernel", 6: "conv_small_kernel", 7: "conv_mid_kernel"}
     esz = {hip.F32: 4, hip.BF16: 2, hip.F16: 2}
     acc = {}
     ci = 0

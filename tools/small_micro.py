@@ -11,20 +11,26 @@ DEV = "cuda:0"
 BF = torch.bfloat16
 
 
-def build(S, cin, cout, gn, stats, res, tbias, short, B=1):
+def build(S, cin, cout, gn, stats, res, tbias, short, B=1, rows=1):
+    """cin: channels of the 9-tap source, or a list (the sources of a torch.cat); rows: partial rows of the unit sums."""
     g = torch.Generator().manual_seed(0)
-    x = torch.randn(B, S, S, cin, generator=g).to(DEV).to(BF)
-    ws = [(torch.randn(cout, cin, 3, 3, generator=g) / math.sqrt(9 * cin), 9)]
-    keep = [x]
+    cins = list(cin) if isinstance(cin, (list, tuple)) else [cin]
+    ctot = sum(cins)
+    ws, keep = [], []
     ca = hip.ConvArgs()
-    ca.seg[0].src, ca.seg[0].C, ca.seg[0].coff, ca.seg[0].cin, ca.seg[0].taps = x.data_ptr(), cin, 0, cin, 9
-    ca.nseg = 1
+    for i, c in enumerate(cins):
+        x = torch.randn(B, S, S, c, generator=g).to(DEV).to(BF)
+        keep.append(x)
+        ws.append((torch.randn(cout, c, 3, 3, generator=g) / math.sqrt(9 * ctot), 9))
+        ca.seg[i].src, ca.seg[i].C, ca.seg[i].coff, ca.seg[i].cin, ca.seg[i].taps = x.data_ptr(), c, 0, c, 9
+    ca.nseg = len(cins)
     if short:
         sx = torch.randn(B, S, S, short, generator=g).to(DEV).to(BF)
         keep.append(sx)
         ws.append((torch.randn(cout, short, 1, 1, generator=g) / math.sqrt(short), 1))
-        ca.seg[1].src, ca.seg[1].C, ca.seg[1].coff, ca.seg[1].cin, ca.seg[1].taps = sx.data_ptr(), short, 0, short, 1
-        ca.nseg = 2
+        i = ca.nseg
+        ca.seg[i].src, ca.seg[i].C, ca.seg[i].coff, ca.seg[i].cin, ca.seg[i].taps = sx.data_ptr(), short, 0, short, 1
+        ca.nseg = i + 1
     wp, cpad = pack_conv_weight(ws, 64, BF, DEV)
     wf = frag_major(wp)
     bias = torch.randn(cout, generator=g).to(DEV)
@@ -38,13 +44,15 @@ def build(S, cin, cout, gn, stats, res, tbias, short, B=1):
     keep.append(acc)
     if gn:
         G = 32
-        us = torch.randn(B, 1, cin // 4, 2, dtype=torch.float64).abs().to(DEV) + 1.0
-        us[..., 1] = us[..., 0] ** 2 / (S * S * 4) + S * S * 4 * 1.0
-        gam, bet = torch.ones(cin, device=DEV), torch.zeros(cin, device=DEV)
-        keep += [us, gam, bet]
-        ca.gn_seg_sums[0], ca.gn_seg_nsplit[0] = us.data_ptr(), 1
-        ca.gn_gamma, ca.gn_beta, ca.gn_G, ca.gn_C, ca.gn_silu = gam.data_ptr(), bet.data_ptr(), G, cin, 1
-        ca.gn_count, ca.gn_eps, ca.seg_gn_mask = S * S * (cin // G), 1e-6, 1
+        for i, c in enumerate(cins):
+            us = (torch.randn(B, rows, c // 4, 2, dtype=torch.float64).abs().to(DEV) + 1.0) / rows
+            us[..., 1] = (us[..., 0] * rows) ** 2 / (S * S * 4) / rows + S * S * 4 * 1.0 / rows
+            keep.append(us)
+            ca.gn_seg_sums[i], ca.gn_seg_nsplit[i] = us.data_ptr(), rows
+        gam, bet = torch.ones(ctot, device=DEV), torch.zeros(ctot, device=DEV)
+        keep += [gam, bet]
+        ca.gn_gamma, ca.gn_beta, ca.gn_G, ca.gn_C, ca.gn_silu = gam.data_ptr(), bet.data_ptr(), G, ctot, 1
+        ca.gn_count, ca.gn_eps, ca.seg_gn_mask = S * S * (ctot // G), 1e-6, (1 << len(cins)) - 1
     if stats:
         st = torch.zeros(B, 1, cout // 4, 2, dtype=torch.float64, device=DEV)
         keep.append(st)
@@ -78,17 +86,22 @@ def time_graph(ca, n=16, reps=30):
     return ts[len(ts) // 2], hip.lib().fdbm_conv_last_kind()
 
 
-cases = [("plain", {}), ("+gn", dict(gn=True)), ("+gn+stats", dict(gn=True, stats=True)), ("+gn+stats+res+tbias", dict(gn=True, stats=True, res=True, tbias=True)),
-         ("+gn+stats+res+shortcut256", dict(gn=True, stats=True, res=True, short=256))]
-for S in (4, 8):
-    for cin in (256, 512):
-        for name, kw in cases:
-            row = []
-            for pol in (43, 11):
-                old = hip.conv_policy(pol)
-                full = dict(gn=False, stats=False, res=False, tbias=False, short=0); full.update(kw)
-                ca, keep = build(S, cin, 256, **full)
-                t, kind = time_graph(ca)
-                hip.conv_policy(old)
-                row.append(f"kind {kind}: {t:5.2f} us")
-            print(f"{S}x{S} cin {cin:3d} {name:28s} " + "   ".join(row), flush=True)
+def main():
+    cases = [("plain", {}), ("+gn", dict(gn=True)), ("+gn+stats", dict(gn=True, stats=True)), ("+gn+stats+res+tbias", dict(gn=True, stats=True, res=True, tbias=True)),
+             ("+gn+stats+res+shortcut256", dict(gn=True, stats=True, res=True, short=256))]
+    for S in (4, 8):
+        for cin in (256, 512):
+            for name, kw in cases:
+                row = []
+                for pol in (43, 11):
+                    old = hip.conv_policy(pol)
+                    full = dict(gn=False, stats=False, res=False, tbias=False, short=0); full.update(kw)
+                    ca, keep = build(S, cin, 256, **full)
+                    t, kind = time_graph(ca)
+                    hip.conv_policy(old)
+                    row.append(f"kind {kind}: {t:5.2f} us")
+                print(f"{S}x{S} cin {cin:3d} {name:28s} " + "   ".join(row), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -5,7 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from fdbm_amd import hip
-import small_micro as sm   # noqa: E402  (runs its table first; then the stamps)
+import small_micro as sm   # noqa: E402
+
+sm.main()                  # its table first; then the stamps
 
 names = ["start", "weights requested", "map requested", "zeroed / params", "stats done", "map in LDS", "MFMAs done", "partials summed", "epilogue done"]
 for S, cin, kw in ((4, 256, dict(gn=True, stats=True, res=True, tbias=True)), (8, 256, dict(gn=True, stats=True, res=True, tbias=True)),

@@ -183,35 +183,58 @@ __device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int64_t m, i
   }
 }
 
+// a double moved between lanes by a DPP control (both halves), and the sum over the 2 | 4 | 8 | 16 adjacent lanes of a DPP row
+// that share a statistics slot: every step adds two values that were formed the same way, so all lanes of the slot end
+// with the bit-identical total (a + b == b + a)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lanes_sum_d(double v, int L) {
+  if (L >= 2) v += dpp_mov_d<0xB1>(v);      // quad_perm [1,0,3,2]
+  if (L >= 4) v += dpp_mov_d<0x4E>(v);      // quad_perm [2,3,0,1]
+  if (L >= 8) v += dpp_mov_d<0x141>(v);     // row_half_mirror
+  if (L >= 16) v += dpp_mov_d<0x140>(v);    // row_mirror
+  return v;
+}
+
 // GroupNorm prologue table: per (image of this workgroup, channel) scale and shift from the partial
 // (sum, sumsq) rows the producer left, as TWO arrays (scale at s_gn[i], shift at s_gn[shoff + i],
 // i = bl * gn_C + c; adjacent channels adjacent, so that the transform runs on packed-f32 instructions):
 // scale = rstd * gamma, shift = beta - mean * rstd * gamma.
-// The |gn_nsplit| partial rows of an (image, group) are dealt out over NTHR / (32 nb) threads (a single
-// thread walking 16-64 rows one load after the other costs 5-20 us of pure latency), the partials are
-// summed in fp64 in a fixed order.  `scratch` is any LDS the kernel is not using yet
-// (>= NTHR * 16 bytes), s_mr holds [nb][32][2] floats.  Ends with a barrier.
+// An (image, group) slot belongs to L ADJACENT lanes (L = 16 | 8 | 4 | 2: NTHR / (32 nb) rounded down to a power of
+// two): each lane sums every L-th of the slot's partial rows / (unit, row) items in fp64 with two loads in flight, a DPP
+// reduction (lanes_sum_d) leaves the same total in all of them, each computes mean and 1 / sqrt and writes the scale / shift
+// of every L-th channel of the group - fixed order, ONE barrier, no LDS partials.  (Round 2's form - partials to LDS, a
+// barrier, one thread per slot summing them, a barrier, the table, a barrier - put 1.5-2 us of barriers and serial LDS
+// round trips at the head of every GroupNorm'd launch: tools/tap_timeline.py "gn table".)
+// s_mr / scratch: no longer used (kept in the signature for the callers' LDS maps).  Ends with a barrier.
 template <int NTHR>
 __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int nb, float* s_gn, int shoff, float* s_mr,
                                               unsigned char* scratch) {
+  static_assert(NTHR == 128 || NTHR == 256 || NTHR == 512 || NTHR == 1024, "conv_gn_table: 128 ... 1024 threads");
+  (void)s_mr; (void)scratch;
   const int tid = threadIdx.x;
   const int G = p.gn_G, C = p.gn_C;
-  const int nslot = nb * 32;
-  const int nparts = NTHR / nslot;                 // >= 2 (nb <= 4, NTHR >= 256)
-  const int slot = tid % nslot, part = tid / nslot;
+  constexpr int LOGN = NTHR == 128 ? 7 : NTHR == 256 ? 8 : NTHR == 512 ? 9 : 10;
+  const int lsh = min(4, LOGN - 5 - (nb == 1 ? 0 : nb == 2 ? 1 : 2));        // log2 L: NTHR / (32 images) lanes (nb <= 4), at most a DPP row
+  const int L = 1 << lsh;
+  const int slot = tid >> lsh, j = tid & (L - 1);
   const int bl = slot >> 5, g = slot & 31;
-  double* red = reinterpret_cast<double*>(scratch);
+  const bool act = bl < nb && g < G;
+  const int cpg = C / G;
   const int nsp = p.gn_nsplit < 0 ? -p.gn_nsplit : p.gn_nsplit;
-  // gamma / beta of this thread's first two table entries: requested now, beside the statistics rows,
-  // instead of after the two barriers below (one exposed memory round trip less per launch)
-  const int ce0 = tid % C, ce1 = (tid + NTHR) % C;
-  const float g0 = p.gn_gamma[ce0], be0 = p.gn_beta[ce0], g1 = p.gn_gamma[ce1], be1 = p.gn_beta[ce1];
+  // gamma / beta of this lane's first channel: requested now, beside the statistics rows
+  const int ce0 = act ? g * cpg + min(j, cpg - 1) : 0;
+  const float g0 = p.gn_gamma[ce0], be0 = p.gn_beta[ce0];
   double a0 = 0.0, a1 = 0.0, c0 = 0.0, c1 = 0.0;
-  if (g < G && part < nparts && p.gn_unit) {
+  if (act && p.gn_unit) {
     // units of 4 channels, one buffer per segment: group g = units [g * upg, (g + 1) * upg).  The group's
-    // upg x (rows of its segment) partial sums are dealt out item by item over the parts, two loads in
-    // flight per thread (with 16 parts a thread usually owns one item: one memory round trip)
-    const int upg = (C / G) >> 2;
+    // upg x (rows of its segment) partial sums are dealt out item by item over the slot's lanes
+    const int upg = cpg >> 2;
     auto item = [&](int t, double& s0, double& s1) __attribute__((always_inline)) {
       // t -> (unit u = g * upg + t % upg, row t / upg); rows beyond the unit's segment add nothing
       const int u = g * upg + t % upg, sp = t / upg;
@@ -230,63 +253,53 @@ __device__ __forceinline__ void conv_gn_table(const ConvParams& p, int b0, int n
     if (p.seg_gn[2] >= 0) maxsp = max(maxsp, p.gn_unsp[2]);
     if (p.seg_gn[3] >= 0) maxsp = max(maxsp, p.gn_unsp[3]);
     const int T = upg * maxsp;
-    for (int t = part; t < T; t += 2 * nparts) {
+    for (int t = j; t < T; t += 2 * L) {
       double x0, x1, y0 = 0.0, y1 = 0.0;
       item(t, x0, x1);
-      if (t + nparts < T) item(t + nparts, y0, y1);
+      if (t + L < T) item(t + L, y0, y1);
       a0 += x0; a1 += x1; c0 += y0; c1 += y1;
     }
-  } else if (g < G && part < nparts) {
+  } else if (act) {
     if (p.gn_nsplit < 0) {
       const double* sd = reinterpret_cast<const double*>(p.gn_sums) + (((int64_t)(b0 + bl)) * nsp * G + g) * 2;
-      int sp = part;
-      for (; sp + nparts < nsp; sp += 2 * nparts) {
+      int sp = j;
+      for (; sp + L < nsp; sp += 2 * L) {
         const double* q = sd + (int64_t)sp * G * 2;
-        const double* r = sd + (int64_t)(sp + nparts) * G * 2;
+        const double* r = sd + (int64_t)(sp + L) * G * 2;
         a0 += q[0]; a1 += q[1]; c0 += r[0]; c1 += r[1];
       }
       if (sp < nsp) { const double* q = sd + (int64_t)sp * G * 2; a0 += q[0]; a1 += q[1]; }
     } else {
       const float* sf = p.gn_sums + (((int64_t)(b0 + bl)) * nsp * G + g) * 2;
-      int sp = part;
-      for (; sp + nparts < nsp; sp += 2 * nparts) {
+      int sp = j;
+      for (; sp + L < nsp; sp += 2 * L) {
         const float* q = sf + (int64_t)sp * G * 2;
-        const float* r = sf + (int64_t)(sp + nparts) * G * 2;
+        const float* r = sf + (int64_t)(sp + L) * G * 2;
         a0 += (double)q[0]; a1 += (double)q[1]; c0 += (double)r[0]; c1 += (double)r[1];
       }
       if (sp < nsp) { const float* q = sf + (int64_t)sp * G * 2; a0 += (double)q[0]; a1 += (double)q[1]; }
     }
   }
-  if (part < nparts) {
-    red[(part * nslot + slot) * 2] = a0 + c0;
-    red[(part * nslot + slot) * 2 + 1] = a1 + c1;
-  }
-  __syncthreads();
-  if (tid < nslot && g < G) {
-    double t0 = 0.0, t1 = 0.0;
-    for (int q = 0; q < nparts; ++q) { t0 += red[(q * nslot + slot) * 2]; t1 += red[(q * nslot + slot) * 2 + 1]; }
-    const double mean = t0 * p.gn_inv_count;
-    double var = t1 * p.gn_inv_count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mr[2 * slot] = (float)mean;
-    // 1 / sqrt in fp64 as v_rsq_f64 + one Newton step (error ~1e-15, far below the float it is rounded to)
-    // instead of the sqrt + division sequences (~40 instructions on the launch's critical path)
-    const double x = var + (double)p.gn_eps;
-    double r = __builtin_amdgcn_rsq(x);
-    r = r * (1.5 - 0.5 * x * r * r);
-    s_mr[2 * slot + 1] = (float)r;
-  }
-  __syncthreads();
-  const int cpg = C / G;
-  const float inv_cpg = 1.0f / (float)cpg, inv_C = 1.0f / (float)C;     // (exact quotients for these small integers)
-  for (int i = tid, it = 0; i < nb * C; i += NTHR, ++it) {
-    const int ib = nb == 1 ? 0 : (int)(((float)i + 0.5f) * inv_C), c = i - ib * C;
-    const int gg = (int)(((float)c + 0.5f) * inv_cpg);
-    const float ga = it == 0 ? g0 : it == 1 ? g1 : p.gn_gamma[c];
-    const float be = it == 0 ? be0 : it == 1 ? be1 : p.gn_beta[c];
-    const float sc = s_mr[2 * (ib * 32 + gg) + 1] * ga;
-    s_gn[i] = sc;
-    s_gn[shoff + i] = be - s_mr[2 * (ib * 32 + gg)] * sc;
+  // (every lane takes part in the exchange: a lane outside `act` contributes to no live slot)
+  const double t0 = lanes_sum_d(a0 + c0, L), t1 = lanes_sum_d(a1 + c1, L);
+  const double mean = t0 * p.gn_inv_count;
+  double var = t1 * p.gn_inv_count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  // 1 / sqrt in fp64 as v_rsq_f64 + one Newton step (error ~1e-15, far below the float it is rounded to)
+  // instead of the sqrt + division sequences (~40 instructions on the launch's critical path)
+  const double x = var + (double)p.gn_eps;
+  double r = __builtin_amdgcn_rsq(x);
+  r = r * (1.5 - 0.5 * x * r * r);
+  const float mf = (float)mean, rf = (float)r;
+  if (act) {
+    for (int cc = j; cc < cpg; cc += L) {
+      const int c = g * cpg + cc;
+      const float ga = cc == j ? g0 : p.gn_gamma[c];
+      const float be = cc == j ? be0 : p.gn_beta[c];
+      const float sc = rf * ga;
+      s_gn[bl * C + c] = sc;
+      s_gn[shoff + bl * C + c] = be - mf * sc;
+    }
   }
   __syncthreads();
 }

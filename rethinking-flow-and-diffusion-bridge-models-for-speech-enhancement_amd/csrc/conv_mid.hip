@@ -144,22 +144,6 @@ static bool mid_plan(const ConvParams& p, MidArgs* out) {
 template <typename T>
 __device__ __forceinline__ uint4 mld16(const T* p) { return *reinterpret_cast<const uint4*>(p); }
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_d(double v) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-// sum over the 16 lanes of a DPP row; every step adds two values that were formed the same way, so all lanes end bit-identical
-__device__ __forceinline__ double row16_sum_d(double v) {
-  v += dpp_d<0xB1>(v);
-  v += dpp_d<0x4E>(v);
-  v += dpp_d<0x141>(v);
-  v += dpp_d<0x140>(v);
-  return v;
-}
-
 template <typename T, typename TO, bool GNP>
 __global__ void __launch_bounds__(MID_NTHR) conv_mid_kernel(const MidArgs a, TO* __restrict__ out, double* __restrict__ stat_out,
                                                             int stat_G, int stat_nsplit) {
@@ -259,7 +243,7 @@ __global__ void __launch_bounds__(MID_NTHR) conv_mid_kernel(const MidArgs a, TO*
     for (int i = tid; i < 128; i += MID_NTHR) s_ostat[i] = 0.0;
   if constexpr (GNP) {
     double s0 = (st0[0] + st0[1]) + (st0[2] + st0[3]), s1 = (st1[0] + st1[1]) + (st1[2] + st1[3]);
-    s0 = row16_sum_d(s0); s1 = row16_sum_d(s1);
+    s0 = lanes_sum_d(s0, 16); s1 = lanes_sum_d(s1, 16);
     const double mean = s0 * a.inv_count_d;
     double var = s1 * a.inv_count_d - mean * mean;
     var = var < 0.0 ? 0.0 : var;

@@ -44,6 +44,9 @@ def run(B, H, W, cin, cout, gn):
     nch = (cin + 63) // 64
     names = {0: "start", 1: "loads issued", 2: "gn table", 3: "patch0 in LDS"}
     print(f"B{B} {H}x{W} {cin}->{cout} gn={int(gn)} plan={hip.conv_plan_ex(B, H, W, cout, 9 * nch, 9)} launch {a.elapsed_time(b_) * 1e3:.1f} us")
+    if hip.lib().fdbm_conv_last_kind() != 2 or st[29] == st[0]:
+        print("   (another kernel family took this shape: no wave-per-tap stamps; FDBM_CONV_MID=0 / FDBM_CONV_SMALL=0 select it)")
+        return
     # calibrate the s_memtime tick with s_memrealtime (100 MHz) taken at the first and last stamp
     ns_per_tick = (st[61] - st[60]) * 10.0 / max(1, st[29] - st[0])
     print(f"   shader clock {1e3 / ns_per_tick:.0f} MHz")

@@ -166,8 +166,33 @@ def bench(reps=30):
     hip.conv_policy(11)
 
 
+def tail(reps=20):
+    """The 1-tap tail (the res-block's 1x1 shortcut in the same accumulator): launches with and without it, batch 1 and 16.
+    A/B of the tail prefetch: STAMPS=0 VARIANTS=NOPF bash tools/build_ring_variants.sh; FDBM_HIP_LIB=tools/_dbg/libfdbm_NOPF.so"""
+    hip.conv_policy(11)
+    for B in (1, 16):
+        for H, cout, cins, short in ((256, 128, [128], []), (256, 128, [128], [128]), (256, 128, [128], [128, 128]),
+                                     (128, 256, [256], []), (128, 256, [256], [256]), (128, 256, [256], [256, 256]),
+                                     (128, 128, [128], [256, 128])):
+            ca, out, ref, st, keep = make(B, H, H, cins, cout, short=short, gn=True, stat=True, res=True)
+            for _ in range(3):
+                hip.call("fdbm_conv_igemm", ca)
+            torch.cuda.synchronize()
+            a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                hip.call("fdbm_conv_igemm", ca)
+            b_.record(); torch.cuda.synchronize()
+            us = a.elapsed_time(b_) * 1e3 / reps
+            fl = 2.0 * B * H * H * cout * (9 * sum(cins) + sum(short))
+            err = (out.float() - ref).abs().max().item()
+            print(f"B{B} {H}x{H} {cins}+{short}->{cout}: kind {hip.lib().fdbm_conv_last_kind()} {us:7.1f} us {fl / us / 1e6:6.1f} TF/s  max err {err:.3g}", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "bench"]
+    if "tail" in what:
+        tail()
     if "check" in what:
         check()
     if "bench" in what:

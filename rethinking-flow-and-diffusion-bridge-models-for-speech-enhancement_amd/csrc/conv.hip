@@ -563,6 +563,8 @@ int fdbm_launch_conv_small(const ConvParams& p, int dt_in, int dt_out, hipStream
 bool fdbm_conv_small_ok(const ConvParams& p, bool f32_out);
 int fdbm_launch_conv_mid(const ConvParams& p, int dt_in, int dt_out, hipStream_t st);                    // conv_mid.hip
 bool fdbm_conv_mid_ok(const ConvParams& p);
+int fdbm_launch_conv_small_split(const ConvParams& p, hipStream_t st);                                   // conv_small_split.hip
+bool fdbm_conv_small_split_ok(const ConvParams& p);
 bool fdbm_conv_head_ok(const ConvParams& p);
 
 // Which kernel runs a conv of this shape: kind 1 = halo-patch 3x3 kernel (conv_patch.hip, tile
@@ -752,6 +754,13 @@ extern "C" int fdbm_conv_igemm(const fdbm_conv_args* a, void* stream) {
     static const char* fth = getenv("FDBM_PATCH_TH");          // experiments: "16" keeps the plan's choice
     if (!(fth && fth[0] == '1') && (!a->gn_sums && !gn_units ? true : a->gn_C <= 256)) th = 8;
     return fdbm_launch_conv_patch(p, a->dt_in, a->dt_out, th, st);
+  }
+  if (kind == 2 && (conv_policy() & 32) && p.mma_split && a->w_frag) {
+    // the same maps in the split-precision parity mode: f32 tensors, (hi, lo) f16 operand pairs (conv_small_split.hip)
+    ConvParams ps = p;
+    ps.w = a->w_frag;
+    ps.ksplit = 1;
+    if (fdbm_conv_small_split_ok(ps)) { g_last_kind = 6; return fdbm_launch_conv_small_split(ps, st); }
   }
   if (kind == 2 && (conv_policy() & 32) && a->dt_in != FDBM_F32) {
     // the smallest maps (4 x 4, 8 x 8 at batch 1): whole map per workgroup, GroupNorm statistics by the consumer (conv_small.hip)

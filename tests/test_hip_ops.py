@@ -633,7 +633,12 @@ def test_conv_tap_chunk_remainders(cin, cin1, HW, dtype, splitk, policy):
         hip.conv_policy(old)
     # policy 43 (the default): the whole-map kernel takes the 16-bit cases whose map and channel counts it accepts
     small_ok = policy == 43 and dtype == torch.bfloat16 and cin in (256, 512) and cin1 % 64 == 0      # (16 x 16: its band form)
-    assert kind == (6 if small_ok else 2), (kind, small_ok)
+    if run_dtype == F32S and policy == 43 and cin in (256, 512) and cin1 % 64 == 0:
+        # the split-precision form of that kernel (conv_small_split.hip): 256 staged channels always; 512 where the staged rows,
+        # twice the bytes of the 16-bit form, still fit the LDS beside the shortcut's pixels
+        assert kind == 6 or (cin == 512 and kind == 2), kind
+    else:
+        assert kind == (6 if small_ok else 2), (kind, small_ok)
     err = (out - ref).abs().max().item()
     assert err < (2e-5 if dtype == torch.float32 else 2e-2), err
 

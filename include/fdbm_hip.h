@@ -263,8 +263,10 @@ typedef struct {
   int32_t stat_nsplit;
   /* optional: the same packed weights in MFMA-fragment-major order
    * [kstep][CoutPad/16][8 chunks][16 rows][16 bytes] (row r, chunk c of `w` moves to
-   * [r/16][c][r%16]); the wave-per-tap kernel (plan kind 2) loads its operand fragments straight
-   * from it with 1 KiB-contiguous wave loads.  NULL: kind 2 is never selected. */
+   * [r/16][c][r%16]); the wave-per-tap kernel (plan kind 2) and the kernels that take its place on
+   * the small launches - whole-map / band (csrc/conv_small.hip, conv_small_split.hip), 64-channel
+   * block (csrc/conv_mid.hip) - load their operand fragments straight from it with 1 KiB-contiguous
+   * wave loads.  NULL: kind 2 is never selected. */
   const void* w_frag;
   /* optional, instead of gn_sums: UNIT statistics of the GroupNorm input, one buffer per flagged
    * segment s: gn_seg_sums[s] = double [B][gn_seg_nsplit[s]][cin_s/4][2], (sum, sumsq) over units of

@@ -158,7 +158,8 @@ static bool small_plan(const ConvParams& p, SmallArgs* out, int* lds_bytes, int*
   // a latency kernel: every workgroup re-reads its 16 output channels' weights and re-stages the rows it needs, which only pays
   // while the launch is a few hundred workgroups (batch 1: every level up to 32 x 32; batch 64: the 4 x 4 level) - beyond
   // that the wave-per-tap kernel's wider tiles win (batch 64: 3.4 ms per forward on this kernel against 0.9 ms)
-  if ((int64_t)((p.Cout + 15) / 16) * (a.HW / (16 * mt)) * p.B > 512) return false;
+  static const char* mxg = getenv("FDBM_SMALL_MAX_GRID");          // experiments
+  if ((int64_t)((p.Cout + 15) / 16) * (a.HW / (16 * mt)) * p.B > (mxg ? atoi(mxg) : 512)) return false;
   *mt_out = mt;
   a.ks1 = a.c1 / 32;
   a.pooled = (a.c9 ? a.c9 / 32 : 0) + a.ks1;                       // tap 8 (or the centre tap) of the staged channels + the raw ones

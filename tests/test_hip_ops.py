@@ -718,15 +718,17 @@ def test_conv_fused_gn_combine_stats(case, dtype, splitk, conv_kernels, units):
     assert ((st - ref_st).abs() <= 1e-4 * (1 + ref_st.abs()) * (10 if dtype == torch.bfloat16 else 1)).all(), name
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, F32S])
 @pytest.mark.parametrize("S", [4, 8, 16, 32])
 def test_conv_small_pyramid_head(S, dtype):
-    """The 4-channel f32 pyramid heads of the small levels on the whole-map / band kernel (conv_small.hip): GroupNorm + SiLU
-    prologue (unit statistics), conv3x3(256 -> 4), the half-resolution pyramid upsampled into the epilogue, f32 output
-    (ncsnpp_v2.py:372-389).  The kernel must be the one that ran (kind 6), against torch and against the wave-per-tap
-    kernel on the same inputs."""
+    """The 4-channel f32 pyramid heads of the small levels on the whole-map / band kernel (conv_small.hip; in the
+    split-precision mode conv_small_split.hip): GroupNorm + SiLU prologue (unit statistics), conv3x3(256 -> 4), the
+    half-resolution pyramid upsampled into the epilogue, f32 output (ncsnpp_v2.py:372-389).  The kernel must be the one that
+    ran (kind 6), against torch and against the wave-per-tap kernel on the same inputs."""
     B, C, cout = 2, 256, 4
     x = rnd(B, C, S, S, seed=S) * 1.3 + 0.1
+    run_dtype = dtype
+    dtype = norm_dtype(dtype)[0]
     q = lambda t: t.to(dtype).float()
     gamma, beta = rnd(C, seed=3) * 0.1 + 1, rnd(C, seed=4) * 0.1
     w = rnd(cout, C, 3, 3, seed=20) / math.sqrt(C * 9)
@@ -738,14 +740,14 @@ def test_conv_small_pyramid_head(S, dtype):
     for pol in (43, 11):
         old = hip.conv_policy(pol)
         try:
-            outs[pol], _, _ = run_conv([(x, 9)], [w], bias, dtype, out_dtype=torch.float32, res_up=r, scale=1.0,
+            outs[pol], _, _ = run_conv([(x, 9)], [w], bias, run_dtype, out_dtype=torch.float32, res_up=r, scale=1.0,
                                        gn=(32, gamma, beta, True, 1, True))
             kind = hip.lib().fdbm_conv_last_kind()
         finally:
             hip.conv_policy(old)
         assert kind == (6 if pol == 43 else 2), (pol, kind)
-        assert (outs[pol] - ref).abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 4e-3), (pol, S)
-    assert (outs[43] - outs[11]).abs().max().item() < 5e-3
+        assert (outs[pol] - ref).abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 4e-3 if dtype == torch.float16 else 2e-5), (pol, S)
+    assert (outs[43] - outs[11]).abs().max().item() < (5e-3 if dtype != torch.float32 else 1e-5)
 
 
 MID_CASES = [
@@ -760,6 +762,9 @@ MID_CASES = [
     ("sc128_cout128_b2", 2, 64, 64, [128], [128], 128, True),
     ("b2_32x64", 2, 32, 64, [256], [128], 256, True),
     ("b6_16x32_edges", 6, 16, 32, [256, 256], [], 256, True),       # every tile touches an image border
+    ("odd_20x48_b8", 8, 20, 48, [128, 128], [], 128, True),         # 5 x 3 tiles per image, two 128-channel passes
+    ("sc64_20x48_b8", 8, 20, 48, [256], [64], 128, True),           # ... a 64-channel shortcut (2 k-steps over the 8 waves)
+    ("c64_plain", 1, 64, 64, [64], [64], 256, False),               # a 64-channel pass (2 k-steps)
 ]
 
 

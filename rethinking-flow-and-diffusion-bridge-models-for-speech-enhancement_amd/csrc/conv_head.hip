@@ -116,9 +116,14 @@ __global__ void __launch_bounds__(256, 2) conv_head_kernel(const ConvParams p, i
       // the next patch (next chunk, or the next tile's first chunk) is requested before this chunk is multiplied
       if (c + 1 < nch) load_patch(ti, c + 1);
       else if (ti + wgs_per_image < tpi) load_patch(ti + wgs_per_image, 0);
+      // (one filter row at a time: fully unrolled, hipcc hoisted all 72 fragment reads of a chunk in front of its MFMAs - 256
+      // registers and 39-51 spills, the patch transform's operands among them)
+#pragma unroll 1
+      for (int k3 = 0; k3 < 3; ++k3) {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        const int dy = k / 3, dx = k % 3;
+      for (int kx = 0; kx < 3; ++kx) {
+        const int k = k3 * 3 + kx;
+        const int dy = k3, dx = kx;
         const int ks = k * nch + c;          // packed k-step order of a 9-tap segment: tap-major, chunk-minor
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -131,6 +136,7 @@ __global__ void __launch_bounds__(256, 2) conv_head_kernel(const ConvParams p, i
             Mfma<T>::run(wf, af, acc[i]);
           }
         }
+      }
       }
     }
     // epilogue: lane (frow, fk) holds channels 4 fk .. 4 fk + 3 of pixel (row 4 wave + i, column frow)

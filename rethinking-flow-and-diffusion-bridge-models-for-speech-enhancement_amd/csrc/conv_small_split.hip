@@ -10,7 +10,8 @@
 //   * a 16-byte item is 4 channels = one statistics unit; a 32-channel k-step is a 128-byte LDS row [32 halves hi | 32 halves lo]
 //     (the operand layout of conv_tap.hip's split mode), a staged pixel is KS9 such rows + 16 bytes;
 //   * weights: fragment-major split pack [k-step][CoutPad / 16][8 chunks][16 rows][16 B], chunks 0-3 = hi, 4-7 = lo;
-//   * band form of the 32 x 32 level: TWO column tiles (one image row) per workgroup - the staged rows are twice the bytes.
+//   * a band form of the 32 x 32 level exists (TWO column tiles = one image row per workgroup: the staged rows are twice the
+//     bytes) but loses to the wave-per-tap kernel there and is not selected (split_plan).
 // In the parity mode these launches were the wave-per-tap kernel's (98 per batch-1 forward at 23 us: profiles/r03/
 // kernel_stats_b1_f32s.csv); results agree with it to fp32 rounding of the sums (tests/test_hip_ops.py, policy 43 vs 11).
 #include "conv_common.h"
@@ -107,6 +108,11 @@ static bool split_plan(const ConvParams& p, SplitArgs* out, int* lds_bytes, int*
     if (gn && !p.gn_unit) return false;
     if (a.HW > 1024) return false;
     mt = a.HW > 256 ? 2 : 1;
+    // (the two-tile form of the 32 x 32 level is built but NOT selected: 16 staged items per thread, 512 workgroups - 29.7 us per
+    //  launch, and the mode's RTF is 34.1-34.3 with it against 34.7-35.0 with that level on the wave-per-tap kernel; FDBM_SPLIT_MT2=1
+    //  selects it)
+    static const char* mt2 = getenv("FDBM_SPLIT_MT2");
+    if (mt == 2 && !(mt2 && mt2[0] == '1')) return false;
     const int pg = 16 * mt;
     if (!(pg % p.W == 0 || p.W % pg == 0) || a.HW % pg != 0) return false;
     a.band = 1;

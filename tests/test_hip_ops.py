@@ -745,7 +745,8 @@ def test_conv_small_pyramid_head(S, dtype):
             kind = hip.lib().fdbm_conv_last_kind()
         finally:
             hip.conv_policy(old)
-        assert kind == (6 if pol == 43 else 2), (pol, kind)
+        # (split-precision mode: the 32 x 32 level stays on the wave-per-tap kernel - conv_small_split.hip, split_plan)
+        assert kind == (6 if pol == 43 and not (run_dtype == F32S and S == 32) else 2), (pol, kind)
         assert (outs[pol] - ref).abs().max().item() < (2e-2 if dtype == torch.bfloat16 else 4e-3 if dtype == torch.float16 else 2e-5), (pol, S)
     assert (outs[43] - outs[11]).abs().max().item() < (5e-3 if dtype != torch.float32 else 1e-5)
 

@@ -148,6 +148,8 @@ static bool small_plan(const ConvParams& p, SmallArgs* out, int* lds_bytes, int*
     if (gn && !p.gn_unit) return false;                            // (statistics of an explicit pass: the general kernels)
     if (a.HW > 1024) return false;
     mt = a.HW > 256 ? 4 : 1;
+    static const char* bmax = getenv("FDBM_SMALL_BAND_MAXHW");       // experiments: largest map of the band form (default 1024)
+    if (bmax && a.HW > atoi(bmax)) return false;
     const int pg = 16 * mt;
     if (!(pg % p.W == 0 || p.W % pg == 0) || a.HW % pg != 0) return false;
     a.band = 1;

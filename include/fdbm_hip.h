@@ -320,8 +320,11 @@ int fdbm_conv_plan_ex(int B, int H, int W, int Cout, int nk, int first_taps, int
  * allows kind 2, bit 2 turns on k-groups inside the kind-0 kernel, bit 3 lets the producer / consumer
  * ring kernel (csrc/conv_ring_impl.h: 16-bit tensors; 16 x 16 pixel tiles when the launch has >= 200 of them,
  * else 8 x 16 pixel tiles when it has >= 128 of those) take the place of kinds 1 and 2, bit 4 makes it use
- * 8 x 16 pixel tiles wherever they fit (tests); mask < 0 only queries.  Returns the previous mask
- * (default 11).  Results are the same convolution under every policy. */
+ * 8 x 16 pixel tiles wherever they fit (tests), bit 5 lets the lean kernels of the small launches take kind 2's place
+ * where their shapes allow (csrc/conv_small.hip: whole-map / band, <= 512 workgroups, maps up to 32 x 32;
+ * csrc/conv_small_split.hip: the same in mma_mode 1; csrc/conv_mid.hip: 192-512 tiles of 4 x 16 pixels x 64 channels,
+ * the 64 x 64 level at batch 1); mask < 0 only queries.  Returns the previous mask (default 43 = bits 0, 1, 3, 5).
+ * Results are the same convolution under every policy. */
 int fdbm_conv_policy(int mask);
 /* kernel family of the most recent fdbm_conv_igemm launch of this process: 0 tap-outer implicit GEMM,
  * 1 halo-patch, 2 wave-per-tap, 3 ring (16 x 16 pixel tiles), 4 ring (8 x 16 pixel tiles), 5 head (<= 16 f32 output

@@ -9,7 +9,11 @@
 //     of ks*C floats (row stride C): no unfolded tensor is ever materialised;
 //   * ConvTranspose1d(2H -> C, ks) is the same on a zero-padded [L + 2(ks-1)][2H] sequence buffer;
 //   * LayerNorm over C, the per-head E-normalisation and the 1x1 convolutions are row operations.
+#include <stdint.h>
+#include <stdlib.h>
+
 #include "common.h"
+#include "conv_common.h"      // Mfma<f16_t>, split_f16x4: the split-precision operand pairs
 
 namespace {
 
@@ -262,6 +266,117 @@ __global__ void __launch_bounds__(256) tfg_gemm(const GemmArgs g) {
         if (g.res) v += g.res[ooff + n];
         out[ooff + n] = v;
       }
+  }
+}
+
+// The same GEMM with every product on the 16-bit matrix pipe (round 3): both operands are split into IEEE-half (hi, lo) pairs while
+// they are staged - hi = half(16 x), lo = half(16 x - hi), 22 significant bits, conv_common.h - and a.w = a_hi.w_hi + a_hi.w_lo +
+// a_lo.w_hi: three v_mfma_f32_16x16x32_f16 per 32 k (48 matrix-pipe cycles) where the f32 form spends eight v_mfma_f32_16x16x4_f32
+// (256 cycles); the f32 sums are multiplied by 1 / 256.  Everything else - tiles, windows, epilogue - as above.  LDS rows: 64 rows x
+// [32 halves hi | 32 halves lo] + 16 bytes (conflict-free b128 fragment reads).  |x| <= 4 094 (16 x clamps at the largest half):
+// LayerNorm outputs, LSTM states, normalised Q / K / V, softmax rows and the residual stream are far inside.
+__global__ void __launch_bounds__(256) tfg_gemm_split(const GemmArgs g) {
+  constexpr int RS = 144;
+  __shared__ __attribute__((aligned(16))) unsigned char As[64 * RS], Ws[64 * RS];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wn = wave >> 1;
+  const int64_t m0 = (int64_t)blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;
+  const float* A = g.A + (int64_t)blockIdx.z * g.sA;
+  const float* W = g.W + (int64_t)blockIdx.z * g.sW;
+  float* out = g.out + (int64_t)blockIdx.z * g.sO;
+  f32x4 acc[2][2];                                      // [n-tile][m-tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // loader: thread loads 8 consecutive k of one row (row = tid / 4, k8 = (tid % 4) * 8) for A and for W
+  const int lr = tid >> 2, lq = tid & 3;
+  const int64_t am = m0 + lr;
+  const float* arow = nullptr;
+  if (am < g.M) arow = A + (am / g.rps) * g.seq_stride + (am % g.rps) * (int64_t)g.lda;
+  const int wr = n0 + lr;
+  const float* wrow = wr < g.N ? W + (int64_t)wr * g.K : nullptr;
+  const int fr = lane & 15, fk = lane >> 4;
+  const bool vecA = ((g.lda | g.K) & 3) == 0 && (g.seq_stride & 3) == 0 && (g.sA & 3) == 0 && (reinterpret_cast<uintptr_t>(A) & 15) == 0;
+  const bool vecW = (g.K & 3) == 0 && (g.sW & 3) == 0 && (reinterpret_cast<uintptr_t>(W) & 15) == 0;
+  f32x4 ra[2], rw[2];
+  auto fetch_row = [&](const float* row, bool vec, int k, f32x4 (&r)[2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kk = k + 4 * h;
+      if (row && vec && kk + 3 < g.K) {
+        r[h] = *reinterpret_cast<const f32x4*>(row + kk);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[h][j] = (row && kk + j < g.K) ? row[kk + j] : 0.f;
+      }
+    }
+  };
+  auto stage = [&](unsigned char* dst, const f32x4 (&r)[2]) __attribute__((always_inline)) {
+    uint2 h0, l0, h1, l1;
+    split_f16x4(r[0], h0, l0);
+    split_f16x4(r[1], h1, l1);
+    *reinterpret_cast<uint4*>(dst + lr * RS + lq * 16) = uint4{h0.x, h0.y, h1.x, h1.y};
+    *reinterpret_cast<uint4*>(dst + lr * RS + 64 + lq * 16) = uint4{l0.x, l0.y, l1.x, l1.y};
+  };
+  fetch_row(arow, vecA, lq * 8, ra);
+  fetch_row(wrow, vecW, lq * 8, rw);
+  for (int k0 = 0; k0 < g.K; k0 += 32) {
+    stage(As, ra);
+    stage(Ws, rw);
+    __syncthreads();
+    if (k0 + 32 < g.K) {
+      fetch_row(arow, vecA, k0 + 32 + lq * 8, ra);
+      fetch_row(wrow, vecW, k0 + 32 + lq * 8, rw);
+    }
+    uint4 wh[2], wl[2], ah[2], al[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned char* wp = Ws + (wn * 32 + i * 16 + fr) * RS + fk * 16;
+      const unsigned char* ap = As + (wm * 32 + i * 16 + fr) * RS + fk * 16;
+      wh[i] = *reinterpret_cast<const uint4*>(wp); wl[i] = *reinterpret_cast<const uint4*>(wp + 64);
+      ah[i] = *reinterpret_cast<const uint4*>(ap); al[i] = *reinterpret_cast<const uint4*>(ap + 64);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        Mfma<f16_t>::run(wh[i], ah[j], acc[i][j]);
+        Mfma<f16_t>::run(wh[i], al[j], acc[i][j]);
+        Mfma<f16_t>::run(wl[i], ah[j], acc[i][j]);
+      }
+    __syncthreads();
+  }
+  const float sc = g.scale * (1.0f / (SPLIT_ACT_SCALE * SPLIT_ACT_SCALE));
+  // a lane's 4 results are 4 consecutive n of one m: one 16-byte store (and bias / residual load) where the row layout allows
+  const bool vecO = ((g.ldo | g.N) & 3) == 0 && (g.out_seq_stride & 3) == 0 && (g.sO & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                    (!g.res || (reinterpret_cast<uintptr_t>(g.res) & 15) == 0) && (!g.bias || (reinterpret_cast<uintptr_t>(g.bias) & 15) == 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int64_t m = m0 + wm * 32 + j * 16 + fr;
+    if (m >= g.M) continue;
+    const int64_t ooff = (m / g.rps) * g.out_seq_stride + (m % g.rps) * (int64_t)g.ldo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int nb = n0 + wn * 32 + i * 16 + fk * 4;
+      if (vecO && nb + 3 < g.N) {
+        f32x4 v = acc[i][j] * sc;
+        if (g.bias) v += *reinterpret_cast<const f32x4*>(g.bias + nb);
+        if (g.res) v += *reinterpret_cast<const f32x4*>(g.res + ooff + nb);
+        *reinterpret_cast<f32x4*>(out + ooff + nb) = v;
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = nb + r;
+          if (n >= g.N) continue;
+          float v = acc[i][j][r] * sc + (g.bias ? g.bias[n] : 0.f);
+          if (g.res) v += g.res[ooff + n];
+          out[ooff + n] = v;
+        }
+      }
+    }
   }
 }
 
@@ -554,7 +669,9 @@ static int tfg_gemm_launch(hipStream_t st, float* out, const float* A, const flo
                            int batch = 1, int64_t sA = 0, int64_t sW = 0, int64_t sO = 0, float scale = 1.f) {
   GemmArgs g{out, A, W, bias, res, M, N, K, rps, seq_stride, lda, out_seq_stride, ldo, sA, sW, sO, scale};
   dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)batch);
-  tfg_gemm<<<grid, 256, 0, st>>>(g);
+  static const char* gm = getenv("FDBM_TFG_GEMM");              // experiments: "f32" = the v_mfma_f32_16x16x4_f32 form
+  if (gm && gm[0] == 'f') tfg_gemm<<<grid, 256, 0, st>>>(g);
+  else tfg_gemm_split<<<grid, 256, 0, st>>>(g);
   FDBM_LAUNCH_CHECK("fdbm_tfgridnet_forward(gemm)");
   return 0;
 }

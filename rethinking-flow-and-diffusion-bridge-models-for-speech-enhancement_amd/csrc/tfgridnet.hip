@@ -180,6 +180,7 @@ struct GemmArgs {
   int rps; int64_t seq_stride; int lda; int64_t out_seq_stride; int ldo;
   int64_t sA, sW, sO;
   float scale;
+  int swap;          // 1: blockIdx.x walks the n-tiles, blockIdx.y the m-tiles
 };
 
 __global__ void __launch_bounds__(256) tfg_gemm(const GemmArgs g) {
@@ -189,8 +190,9 @@ __global__ void __launch_bounds__(256) tfg_gemm(const GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;             // wave's 32 x 32 quadrant of the 64 (m) x 64 (n) tile
-  const int64_t m0 = (int64_t)blockIdx.x * 64;
-  const int n0 = blockIdx.y * 64;
+  // (n-tiles vary fastest: the workgroups in flight together write adjacent 256-byte pieces of the same output rows)
+  const int64_t m0 = (int64_t)(g.swap ? blockIdx.y : blockIdx.x) * 64;
+  const int n0 = (g.swap ? blockIdx.x : blockIdx.y) * 64;
   const float* A = g.A + (int64_t)blockIdx.z * g.sA;
   const float* W = g.W + (int64_t)blockIdx.z * g.sW;
   float* out = g.out + (int64_t)blockIdx.z * g.sO;
@@ -281,8 +283,9 @@ __global__ void __launch_bounds__(256) tfg_gemm_split(const GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave & 1, wn = wave >> 1;
-  const int64_t m0 = (int64_t)blockIdx.x * 64;
-  const int n0 = blockIdx.y * 64;
+  // (n-tiles vary fastest: the workgroups in flight together write adjacent 256-byte pieces of the same output rows)
+  const int64_t m0 = (int64_t)(g.swap ? blockIdx.y : blockIdx.x) * 64;
+  const int n0 = (g.swap ? blockIdx.x : blockIdx.y) * 64;
   const float* A = g.A + (int64_t)blockIdx.z * g.sA;
   const float* W = g.W + (int64_t)blockIdx.z * g.sW;
   float* out = g.out + (int64_t)blockIdx.z * g.sO;
@@ -667,8 +670,10 @@ extern "C" void fdbm_tfgridnet_destroy(fdbm_tfgridnet_ctx* c) { delete c; }
 static int tfg_gemm_launch(hipStream_t st, float* out, const float* A, const float* W, const float* bias, const float* res,
                            int64_t M, int N, int K, int rps, int64_t seq_stride, int lda, int64_t out_seq_stride, int ldo,
                            int batch = 1, int64_t sA = 0, int64_t sW = 0, int64_t sO = 0, float scale = 1.f) {
-  GemmArgs g{out, A, W, bias, res, M, N, K, rps, seq_stride, lda, out_seq_stride, ldo, sA, sW, sO, scale};
-  dim3 grid((unsigned)((M + 63) / 64), (unsigned)((N + 63) / 64), (unsigned)batch);
+  GemmArgs g{out, A, W, bias, res, M, N, K, rps, seq_stride, lda, out_seq_stride, ldo, sA, sW, sO, scale, 0};
+  const int64_t mt = (M + 63) / 64, nt = (N + 63) / 64;
+  g.swap = mt <= 65535;
+  dim3 grid((unsigned)(g.swap ? nt : mt), (unsigned)(g.swap ? mt : nt), (unsigned)batch);
   static const char* gm = getenv("FDBM_TFG_GEMM");              // experiments: "f32" = the v_mfma_f32_16x16x4_f32 form
   if (gm && gm[0] == 'f') tfg_gemm<<<grid, 256, 0, st>>>(g);
   else tfg_gemm_split<<<grid, 256, 0, st>>>(g);
